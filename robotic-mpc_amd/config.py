@@ -1,0 +1,179 @@
+"""Configuration handling: the reference's ``BASE_PARAMS`` dict -> packed parameters.
+
+In the reference the config dict is splatted into ``Simulator(**config)``
+(simulator.py:18-35, 658-659) and from there into ``MPC(...)`` and the acados option
+object (trajectory_optimizer.py:57-70; simulator.py:129-135).  Here the same dict is
+validated and flattened into the per-instance parameter record the C-ABI takes; nothing
+is code-generated.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+from typing import Any, Dict, Mapping, Optional
+
+import numpy as np
+
+# Positional-without-default arguments of Simulator.__init__ (simulator.py:18-27).
+REQUIRED_KEYS = (
+    "robot_name", "dt", "simulation_time", "prediction_horizon", "q_0", "qdot_0", "wcv",
+    "q_min", "q_max", "qdot_min", "qdot_max", "surface_limits", "surface_origin",
+    "surface_orientation_rpy", "w_qddot",
+)
+# Keyword arguments with defaults (simulator.py:30-35).
+OPTIONAL_DEFAULTS = {
+    "surface_coeffs": None, "solver_options": None, "w_u": 0.01, "px_ref": 0.40, "vy_ref": 0.05, "scene": True,
+}
+# Extensions beyond the reference's signature: all optional.
+EXTENSION_DEFAULTS = {"translation_ee_t": (0.0, 0.0, 0.1), "urdf_path": None, "ee_frame": None}
+
+# surface.py:14-17
+DEFAULT_SURFACE_COEFFS = {"a": -0.15, "b": 0.15, "c": -0.01, "d": 0.01, "e": 0.01, "f": 0.0}
+# trajectory_optimizer.py:44-48
+TASK_WEIGHTS = (50.0, 50.0, 50.0, 50.0, 50.0)
+
+SOLVER_SQP, SOLVER_RTI = 0, 1
+
+# acados options set by MPC.__init__ (trajectory_optimizer.py:60-70) + acados defaults.
+DEFAULT_SOLVER_OPTIONS = {
+    "nlp_solver_type": "SQP",
+    "hessian_approx": "GAUSS_NEWTON",
+    "integrator_type": "DISCRETE",
+    "qp_solver": "PARTIAL_CONDENSING_HPIPM",
+    "qp_tol": 1e-8,
+    "tol": 1e-6,
+    "nlp_solver_max_iter": 100,
+    "qp_solver_iter_max": 50,
+    "globalization": "MERIT_BACKTRACKING",
+    "qp_solver_warm_start": 2,
+    "nlp_solver_warm_start_first_qp": True,
+    "print_level": 0,
+}
+# Options the single native QP/NLP implementation accepts but that do not change results.
+_ACCEPTED_NOOP = {
+    "qp_solver", "qp_solver_cond_N", "print_level", "qp_solver_warm_start", "nlp_solver_warm_start_first_qp",
+    "N_horizon", "tf", "qp_solver_cond_ric_alg", "qp_solver_ric_alg", "regularize_method", "ext_fun_compile_flags",
+    "nlp_solver_tol_stat", "nlp_solver_tol_eq", "nlp_solver_tol_ineq", "nlp_solver_tol_comp",
+}
+
+# The common synthetic base of SURVEY.md 8(d) (readme.md:27-43, surface_stats.ipynb cell 1).
+BASE_PARAMS: Dict[str, Any] = {
+    "robot_name": "ur10",
+    "dt": 0.01,
+    "simulation_time": 6,
+    "prediction_horizon": 100,
+    "surface_limits": ((-2, 2), (-2, 2)),
+    "surface_origin": np.array([0.0, 0.0, 0.0]),
+    "surface_orientation_rpy": np.array([0.0, 0.0, 0.0]),
+    "q_0": np.array([np.pi / 4, -np.pi / 3, np.pi / 4, -np.pi / 2, -np.pi / 2, 0.0]),
+    "qdot_0": np.array([1.0, 2.0, 1.0, 0.0, 0.0, 0.0]),
+    "wcv": np.array([200.0] * 6),
+    "q_min": np.array([-2 * np.pi] * 6),
+    "q_max": np.array([+2 * np.pi] * 6),
+    "qdot_min": np.array([-2.16, -2.16, -np.pi, -3.20, -3.20, -3.20]),
+    "qdot_max": np.array([2.16, 2.16, np.pi, 3.20, 3.20, 3.20]),
+    "w_qddot": 0.02,
+    "w_u": 0.01,
+    "px_ref": 0.40,
+    "vy_ref": 0.05,
+    "solver_options": {"nlp_solver_type": "SQP_RTI"},
+    "scene": False,
+}
+
+
+def base_params(**overrides) -> Dict[str, Any]:
+    """A deep copy of BASE_PARAMS with overrides applied."""
+    cfg = copy.deepcopy(BASE_PARAMS)
+    cfg.update(overrides)
+    return cfg
+
+
+def _vec6(cfg: Mapping[str, Any], key: str) -> np.ndarray:
+    v = np.asarray(cfg[key], dtype=np.float64).reshape(-1)
+    if v.shape != (6,):
+        raise ValueError(f"config['{key}'] must have 6 entries, got shape {np.shape(cfg[key])}")
+    if not np.all(np.isfinite(v)):
+        raise ValueError(f"config['{key}'] must be finite")
+    return v
+
+
+def resolve_solver_options(options: Optional[Mapping[str, Any]]) -> Dict[str, Any]:
+    """Mirror of Simulator._apply_solver_options (simulator.py:129-135): known attributes are
+    set, unknown ones only warn."""
+    out = dict(DEFAULT_SOLVER_OPTIONS)
+    if options is None:
+        return out
+    if not isinstance(options, Mapping):
+        raise TypeError("solver_options must be a dict (simulator.py:131 iterates .items())")
+    for key, value in options.items():
+        if key in out or key in _ACCEPTED_NOOP:
+            out[key] = value
+        else:
+            warnings.warn(f"Warning: Unknown solver option '{key}'")
+    if out["nlp_solver_type"] not in ("SQP", "SQP_RTI"):
+        raise ValueError(f"nlp_solver_type '{out['nlp_solver_type']}' not supported (SQP, SQP_RTI)")
+    if out["hessian_approx"] != "GAUSS_NEWTON":
+        raise ValueError("only hessian_approx='GAUSS_NEWTON' is implemented (trajectory_optimizer.py:61)")
+    if out["integrator_type"] != "DISCRETE":
+        raise ValueError("only integrator_type='DISCRETE' is implemented (trajectory_optimizer.py:64)")
+    if out["globalization"] not in ("MERIT_BACKTRACKING", "FIXED_STEP"):
+        raise ValueError(f"globalization '{out['globalization']}' not supported")
+    return out
+
+
+def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
+    """Validate a Simulator(**config) dict and flatten it to solver parameters.
+
+    Raises TypeError for missing/unknown keys exactly where ``Simulator(**config)`` would.
+    """
+    missing = [k for k in REQUIRED_KEYS if k not in config]
+    if missing:
+        raise TypeError(f"Simulator.__init__() missing required arguments: {missing}")
+    known = set(REQUIRED_KEYS) | set(OPTIONAL_DEFAULTS) | set(EXTENSION_DEFAULTS)
+    unknown = [k for k in config if k not in known]
+    if unknown:
+        raise TypeError(f"Simulator.__init__() got unexpected keyword arguments: {unknown}")
+    cfg = {**OPTIONAL_DEFAULTS, **EXTENSION_DEFAULTS, **config}
+
+    dt = float(cfg["dt"])
+    if not dt > 0:
+        raise ValueError("dt must be positive")
+    Nsim = int(float(cfg["simulation_time"]) / dt)  # simulator.py:41
+    N = int(cfg["prediction_horizon"])
+    if N < 1:
+        raise ValueError("prediction_horizon must be >= 1")
+    if Nsim < 1:
+        raise ValueError("simulation_time/dt must give at least one step")
+    coeffs = dict(DEFAULT_SURFACE_COEFFS)
+    if cfg["surface_coeffs"]:
+        extra = set(cfg["surface_coeffs"]) - set(coeffs)
+        if extra:
+            raise KeyError(f"unknown surface coefficient(s) {sorted(extra)}; expected a..f")
+        coeffs.update(cfg["surface_coeffs"])  # surface.py:18-19
+    so = resolve_solver_options(cfg["solver_options"])
+    wcv = _vec6(cfg, "wcv")
+    if np.any(wcv <= 0):
+        raise ValueError("wcv must be positive (prediction_model.py:94 divides by it)")
+    t_ee = np.asarray(cfg["translation_ee_t"], dtype=np.float64).reshape(-1)
+    if t_ee.shape != (3,):
+        raise ValueError("translation_ee_t must have 3 entries")
+    return {
+        "robot_name": cfg["robot_name"], "urdf_path": cfg["urdf_path"], "ee_frame": cfg["ee_frame"],
+        "N": N, "Nsim": Nsim, "dt": dt,
+        "solver_type": SOLVER_RTI if so["nlp_solver_type"] == "SQP_RTI" else SOLVER_SQP,
+        "max_iter": int(so["nlp_solver_max_iter"]), "qp_iter_max": int(so["qp_solver_iter_max"]),
+        "tol": float(so["tol"]), "qp_tol": float(so["qp_tol"]),
+        "fixed_step": so["globalization"] == "FIXED_STEP",
+        "wcv": wcv, "q0": _vec6(cfg, "q_0"), "qdot0": _vec6(cfg, "qdot_0"),
+        "qmin": _vec6(cfg, "q_min"), "qmax": _vec6(cfg, "q_max"),
+        "umin": _vec6(cfg, "qdot_min"), "umax": _vec6(cfg, "qdot_max"),
+        "w_u": float(cfg["w_u"]), "w_qddot": float(cfg["w_qddot"]),
+        "px_ref": float(cfg["px_ref"]), "vy_ref": float(cfg["vy_ref"]),
+        "coeffs": np.array([coeffs[k] for k in "abcdef"], dtype=np.float64),
+        "coeffs_dict": coeffs,
+        "w_task": np.array(TASK_WEIGHTS, dtype=np.float64),
+        "t_ee": t_ee,
+        # stored-but-unused by the OCP, exactly as in the reference
+        "surface_limits": cfg["surface_limits"], "surface_origin": cfg["surface_origin"],
+        "surface_orientation_rpy": cfg["surface_orientation_rpy"],
+    }

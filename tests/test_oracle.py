@@ -1,0 +1,343 @@
+"""Pins the CPU oracle (oracle/mpc_oracle.c) with checks that do not share code with it.
+
+The reference holds no tests or golden vectors and its arithmetic (acados, CasADi,
+Pinocchio) is not installable offline, so these are the anchors:
+closed forms, sympy/numpy kinematics, finite differences, KKT certificates and scipy.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as hp
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- kinematics
+def test_fk_known_answers(orc, ur10_rb):
+    """SURVEY.md Appendix B hand-derived poses (standard URDF convention)."""
+    pose = orc.fk(ur10_rb, np.zeros(6))
+    np.testing.assert_allclose(pose[:3], [1.184300000415, 0.256141, 0.011600002126], atol=1e-9)
+    np.testing.assert_allclose(pose[3:].reshape(3, 3), [[-1, 0, 0], [0, 0, 1], [0, 1, 0]], atol=1e-8)
+    q = np.array([np.pi / 4, -np.pi / 3, np.pi / 4, -np.pi / 2, -np.pi / 2, 0.0])
+    pose = orc.fk(ur10_rb, q)
+    np.testing.assert_allclose(pose[:3], [0.587237391534, 0.819084977163, 0.746316690991], atol=1e-9)
+    zhat = pose[3:].reshape(3, 3)[:, 2]
+    np.testing.assert_allclose(zhat, [0.183012704344, 0.183012704344, -0.96592582536], atol=1e-9)
+    J = orc.jacobian_world(ur10_rb, q)
+    np.testing.assert_allclose(J[:, 1], [-0.090014693245, -0.090014693245, 0, -0.707106781187, 0.707106781187, 0],
+                               atol=1e-9)
+
+
+@pytest.mark.parametrize("robot", ["ur10", "ur5"])
+def test_fk_and_jacobian_vs_homogeneous_chain(orc, robot):
+    from robotic_mpc_amd import robots
+
+    ch = robots.builtin_chain(robot)
+    rb = orc.make_robot(ch)
+    rng = np.random.default_rng(1)
+    for _ in range(16):
+        q = rng.uniform(-np.pi, np.pi, 6)
+        T, origins, axes = hp.fk_homogeneous(ch, q)
+        pose = orc.fk(rb, q)
+        np.testing.assert_allclose(pose[:3], T[:3, 3], atol=1e-13)
+        np.testing.assert_allclose(pose[3:].reshape(3, 3), T[:3, :3], atol=1e-13)
+        J = orc.jacobian_world(rb, q)
+        np.testing.assert_allclose(J, hp.spatial_jacobian_fd(ch, q), atol=5e-9)
+        for i in range(6):
+            np.testing.assert_allclose(J[:3, i], np.cross(origins[i], axes[i]), atol=1e-13)
+            np.testing.assert_allclose(J[3:, i], axes[i], atol=1e-13)
+
+
+def test_fk_sympy_exact(orc, ur10, ur10_rb):
+    """Symbolic chain product evaluated in 50-digit arithmetic."""
+    sp = pytest.importorskip("sympy")
+    qs = sp.symbols("q0:6")
+    T = sp.eye(4)
+    for i in range(6):
+        M = sp.eye(4)
+        M[:3, :3] = sp.Matrix(3, 3, [sp.Float(v, 30) for v in ur10.place[i, :9]])
+        M[:3, 3] = sp.Matrix(3, 1, [sp.Float(v, 30) for v in ur10.place[i, 9:]])
+        a = ur10.axis[i]
+        c, s = sp.cos(qs[i]), sp.sin(qs[i])
+        if a[2] == 1:
+            R = sp.Matrix([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        elif a[1] == 1:
+            R = sp.Matrix([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        else:
+            R = sp.Matrix([[1, 0, 0], [0, c, -s], [0, s, c]])
+        Rj = sp.eye(4)
+        Rj[:3, :3] = R
+        T = T * M * Rj
+    M = sp.eye(4)
+    M[:3, :3] = sp.Matrix(3, 3, [sp.Float(v, 30) for v in ur10.place[6, :9]])
+    M[:3, 3] = sp.Matrix(3, 1, [sp.Float(v, 30) for v in ur10.place[6, 9:]])
+    T = T * M
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        q = rng.uniform(-3, 3, 6)
+        Tn = np.array(T.evalf(30, subs=dict(zip(qs, [sp.Float(v, 30) for v in q]))).tolist(), dtype=float)
+        pose = orc.fk(ur10_rb, q)
+        np.testing.assert_allclose(pose[:3], Tn[:3, 3], atol=2e-15)
+        np.testing.assert_allclose(pose[3:].reshape(3, 3), Tn[:3, :3], atol=2e-15)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+def test_builtin_constants_match_reference_urdf():
+    from robotic_mpc_amd import robots
+
+    for name, frame in (("ur10", "ee_link"), ("ur5", "tool0")):
+        a = robots.builtin_chain(name)
+        b = robots.chain_from_urdf(f"{REF}/ur_description/urdf/{name}.urdf", frame)
+        assert np.array_equal(a.place, b.place) and np.array_equal(a.axis, b.axis)
+
+
+def test_task_functions_and_jacobian(orc, ur10, ur10_rb):
+    rng = np.random.default_rng(3)
+    for _ in range(16):
+        q = rng.uniform(-3, 3, 6)
+        qd = rng.uniform(-2, 2, 6)
+        cf = np.array([-0.15, 0.15, -0.01, 0.01, 0.01, 0.0]) + rng.normal(size=6) * 0.05
+        g, G = orc.task_g(ur10_rb, cf, q, qd)
+        np.testing.assert_allclose(g, hp.task_g_numpy(ur10, cf, q, qd), atol=1e-13)
+        x = np.concatenate([q, qd])
+        Gn = np.zeros((5, 12))
+        for i in range(12):
+            d = np.zeros(12)
+            d[i] = 1e-6
+            Gn[:, i] = (hp.task_g_numpy(ur10, cf, (x + d)[:6], (x + d)[6:]) -
+                        hp.task_g_numpy(ur10, cf, (x - d)[:6], (x - d)[6:])) / 2e-6
+        np.testing.assert_allclose(G, Gn, atol=2e-8)
+        # y (prediction_model.py:313-314): columns of R, R^T(v + w x t_w)
+        y = orc.task_output(ur10_rb, q, qd)
+        T, _, _ = hp.fk_homogeneous(ur10, q)
+        np.testing.assert_allclose(y[3:12], T[:3, :3].T.ravel(), atol=1e-13)
+        assert abs(y[13] - g[4]) < 1e-13 and abs(y[0] - g[3]) < 1e-13
+
+
+# ----------------------------------------------------------------------------- models
+def test_lti_matches_matrix_exponential(orc):
+    from scipy.linalg import expm
+
+    wcv = np.array([200.0, 150.0, 90.0, 20.0, 1.5, 0.3])
+    Ts = 0.01
+    a12, a22, b1, b2 = orc.lti(wcv, Ts)
+    for j in range(6):
+        Ac = np.array([[0, 1, 0], [0, -wcv[j], wcv[j]], [0, 0, 0]])
+        E = expm(Ac * Ts)
+        np.testing.assert_allclose([a12[j], a22[j], b1[j], b2[j]], [E[0, 1], E[1, 1], E[0, 2], E[1, 2]], rtol=1e-12,
+                                   atol=1e-15)
+    # SURVEY.md A.2 scratch values
+    a12, a22, b1, b2 = orc.lti([200.0] * 6, 0.01)
+    assert abs(a22[0] - 0.1353352832366127) < 1e-15 and abs(b1[0] - 0.005676676416183064) < 1e-16
+
+
+def test_rk4_amplification_and_step_response(orc):
+    """RK4 on qdot' = -w(qdot-u) has amplification 1 - h + h^2/2 - h^3/6 + h^4/24, h = w dt
+    (0.3333 for h=2); model.py:185-224's closed form is the exact limit."""
+    w, dt = 200.0, 0.01
+    z = np.zeros(12)
+    z[6:] = 1.0
+    zn = orc.rk4([w] * 6, dt, z, np.zeros(6))
+    h = w * dt
+    np.testing.assert_allclose(zn[6:], 1 - h + h ** 2 / 2 - h ** 3 / 6 + h ** 4 / 24, rtol=1e-14)
+    # small step: converges to the exact step response u(1-exp(-wt))
+    w, dt = 5.0, 1e-3
+    z = np.zeros(12)
+    u = np.full(6, 0.7)
+    for _ in range(100):
+        z = orc.rk4([w] * 6, dt, z, u)
+    t = 0.1
+    np.testing.assert_allclose(z[6:], 0.7 * (1 - np.exp(-w * t)), rtol=1e-10)
+    np.testing.assert_allclose(z[:6], 0.7 * t + 0.7 / w * (np.exp(-w * t) - 1), rtol=1e-9)
+
+
+def test_stage_residual_jacobian(orc, ur10_rb):
+    from robotic_mpc_amd import config
+
+    p = orc.make_params(config.resolve_config(config.base_params()))
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-2, 2, 6), rng.uniform(-1, 1, 6)])
+    u = rng.uniform(-1, 1, 6)
+    r, Jr = orc.stage_residual(ur10_rb, p, x, u)
+    c = (1 - np.exp(-2.0)) / 0.01
+    np.testing.assert_allclose(r[5:11], u, atol=0)
+    np.testing.assert_allclose(r[11:], c * (u - x[6:]), rtol=1e-13)
+    w = np.concatenate([u, x])
+    Jn = np.zeros_like(Jr)
+    for i in range(18):
+        d = np.zeros(18)
+        d[i] = 1e-6
+        rp, _ = orc.stage_residual(ur10_rb, p, (w + d)[6:], (w + d)[:6])
+        rm, _ = orc.stage_residual(ur10_rb, p, (w - d)[6:], (w - d)[:6])
+        Jn[:, i] = (rp - rm) / 2e-6
+    np.testing.assert_allclose(Jr, Jn, atol=5e-8)
+
+
+# ----------------------------------------------------------------------------- QP
+@pytest.mark.parametrize("N,tight", [(1, False), (5, False), (20, False), (20, True), (60, True)])
+def test_qp_ipm_kkt_certificate(orc, N, tight):
+    rng = np.random.default_rng(10 + N)
+    H, g, b, A, B, lb, ub, dx0 = hp.random_ocp_qp(rng, N, tight=tight)
+    s = orc.qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-9, iter_max=80)
+    assert s["status"] == 0
+    k = hp.qp_kkt_residuals(H, g, b, A, B, lb, ub, dx0, s["w"], s["pi"], s["lam"], s["t"])
+    assert k["stat"] < 1e-7 and k["prim"] < 1e-8 and k["feas"] < 1e-8 and k["dual"] <= 0 and k["comp"] < 1e-7
+    if tight:  # some bounds must actually be active for the test to mean something
+        act = (s["lam"] > 1e-3).sum()
+        assert act > 0
+
+
+def test_qp_ipm_matches_scipy_dense(orc):
+    """Independent solve of the condensed (u-only) QP with scipy's trust-constr."""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+
+    rng = np.random.default_rng(5)
+    N = 4
+    H, g, b, A, B, lb, ub, dx0 = hp.random_ocp_qp(rng, N, tight=True)
+    # x_k = Phi_k dx0 + sum Gam_kj u_j + c_k
+    nu = 6 * N
+    Sx = [np.zeros((12, nu)) for _ in range(N + 1)]
+    cx = [dx0.copy()]
+    for k in range(N):
+        S = A @ Sx[k]
+        S[:, 6 * k:6 * k + 6] += B
+        Sx[k + 1] = S
+        cx.append(A @ cx[k] + b[k])
+    Hd = np.zeros((nu, nu))
+    gd = np.zeros(nu)
+    for k in range(N + 1):
+        E = np.zeros((18, nu))
+        if k < N:
+            E[:6, 6 * k:6 * k + 6] = np.eye(6)
+        E[6:] = Sx[k]
+        c = np.concatenate([np.zeros(6), cx[k]])
+        Hd += E.T @ H[k] @ E
+        gd += E.T @ (H[k] @ c + g[k])
+    Cq = np.vstack([Sx[k][:6] for k in range(1, N)])
+    lq = np.concatenate([lb[k, 6:] - cx[k][:6] for k in range(1, N)])
+    uq = np.concatenate([ub[k, 6:] - cx[k][:6] for k in range(1, N)])
+    res = minimize(lambda u: 0.5 * u @ Hd @ u + gd @ u, np.zeros(nu), jac=lambda u: Hd @ u + gd,
+                   hess=lambda u: Hd, method="trust-constr",
+                   bounds=Bounds(lb[:N, :6].ravel(), ub[:N, :6].ravel()),
+                   constraints=[LinearConstraint(Cq, lq, uq)],
+                   options=dict(gtol=1e-12, xtol=1e-14, barrier_tol=1e-14, maxiter=3000))
+    s = orc.qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-10, iter_max=80)
+    assert s["status"] == 0
+    np.testing.assert_allclose(s["w"][:N, :6].ravel(), res.x, atol=2e-6)
+
+
+def test_qp_warm_start_reaches_same_solution(orc):
+    rng = np.random.default_rng(6)
+    H, g, b, A, B, lb, ub, dx0 = hp.random_ocp_qp(rng, 10, tight=True)
+    s1 = orc.qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-11, iter_max=80)
+    s2 = orc.qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-11, iter_max=80, warm=(s1["w"], s1["pi"], s1["lam"], s1["t"]))
+    assert s1["status"] == 0 and s2["status"] == 0
+    # weakly active bounds (lam ~ t ~ sqrt(tol)) limit the primal accuracy of any IPM to ~sqrt(tol)
+    np.testing.assert_allclose(s1["w"], s2["w"], atol=2e-5)
+    assert s2["iters"] <= s1["iters"]
+
+
+# ----------------------------------------------------------------------------- NLP / closed loop
+def _cfg(**kw):
+    from robotic_mpc_amd import config
+
+    return config.resolve_config(config.base_params(**kw))
+
+
+def test_sqp_converges_to_nlp_stationary_point(orc, ur10_rb):
+    """Converged full SQP: check NLP KKT with numpy from the (FD-verified) stage Jacobians."""
+    cfg = _cfg(prediction_horizon=6, solver_options={"nlp_solver_type": "SQP", "tol": 1e-9, "qp_tol": 1e-11})
+    p = orc.make_params(cfg)
+    s = orc.Solver(ur10_rb, p)
+    xhat = np.concatenate([cfg["q0"], cfg["qdot0"]])
+    out = s.step(xhat)
+    assert out["status"] == 0 and out["sqp_iter"] >= 2
+    x, u, pi = s.iterate()
+    A, B = hp.lti_matrices(cfg["wcv"], cfg["dt"])
+    W = np.concatenate([cfg["w_task"], [2 * cfg["w_u"]] * 6, [cfg["w_qddot"]] * 6])
+    np.testing.assert_allclose(x[0], xhat, atol=1e-12)
+    cost = 0.0
+    for k in range(6):
+        np.testing.assert_allclose(A @ x[k] + B @ u[k], x[k + 1], atol=1e-10)
+        r, Jr = orc.stage_residual(ur10_rb, p, x[k], u[k])
+        cost += 0.5 * cfg["dt"] * (W * r) @ r
+        grad = cfg["dt"] * Jr.T @ (W * r)
+        gu = grad[:6] + B.T @ pi[k]
+        # inactive bounds -> gradient zero; active -> sign condition
+        for j in range(6):
+            if u[k, j] > cfg["umin"][j] + 1e-6 and u[k, j] < cfg["umax"][j] - 1e-6:
+                assert abs(gu[j]) < 1e-7
+            elif u[k, j] <= cfg["umin"][j] + 1e-6:
+                assert gu[j] > -1e-7
+            else:
+                assert gu[j] < 1e-7
+        if k >= 1:
+            gx = grad[6:] + A.T @ pi[k] - pi[k - 1]
+            assert np.abs(gx).max() < 1e-7
+    np.testing.assert_allclose(pi[5], 0, atol=1e-8)  # no terminal cost
+    assert abs(cost - out["cost"]) < 1e-12
+
+
+def test_sqp_solution_is_a_local_minimum_vs_scipy(orc, ur10_rb):
+    """Same NLS objective and bounds handed to scipy (u-only, dynamics eliminated)."""
+    from scipy.optimize import minimize
+
+    N = 3
+    cfg = _cfg(prediction_horizon=N, solver_options={"nlp_solver_type": "SQP", "tol": 1e-9, "qp_tol": 1e-11})
+    p = orc.make_params(cfg)
+    xhat = np.concatenate([cfg["q0"], cfg["qdot0"]])
+    A, B = hp.lti_matrices(cfg["wcv"], cfg["dt"])
+    W = np.concatenate([cfg["w_task"], [2 * cfg["w_u"]] * 6, [cfg["w_qddot"]] * 6])
+
+    def obj(uf):
+        u = uf.reshape(N, 6)
+        x = xhat.copy()
+        c = 0.0
+        for k in range(N):
+            r, _ = orc.stage_residual(ur10_rb, p, x, u[k])
+            c += 0.5 * cfg["dt"] * (W * r) @ r
+            x = A @ x + B @ u[k]
+        return c
+
+    s = orc.Solver(ur10_rb, p)
+    out = s.step(xhat)
+    _, u, _ = s.iterate()
+    bounds = list(zip(np.tile(cfg["umin"], N), np.tile(cfg["umax"], N)))
+    res = minimize(obj, u.ravel() + 1e-3, method="L-BFGS-B", bounds=bounds, options=dict(ftol=1e-15, gtol=1e-10,
+                                                                                         maxiter=2000))
+    assert out["status"] == 0
+    assert obj(u.ravel()) <= res.fun + 1e-10
+    np.testing.assert_allclose(u.ravel(), res.x, atol=5e-4)
+
+
+@pytest.mark.parametrize("stype", ["SQP_RTI", "SQP"])
+def test_closed_loop_sanity(orc, ur10_rb, stype):
+    """Order-of-magnitude anchors read from the reference's figures:
+    cost decays from ~3 to <1e-3, e1 -> 0 within ~0.3-0.6 s, no solver failures."""
+    cfg = _cfg(prediction_horizon=20, simulation_time=2, solver_options={"nlp_solver_type": stype})
+    o = orc.run(ur10_rb, orc.make_params(cfg))
+    assert (o["status"] == 0).all()
+    assert 1.0 < o["cost"][0] < 10.0 and o["cost"][-1] < 5e-2
+    pose = o["ee_pose"]
+    pt = pose[:3] + 0.1 * pose[[5, 8, 11]]
+    c = cfg["coeffs"]
+    e1 = c[0] * pt[0] ** 2 + c[1] * pt[1] ** 2 + c[2] * pt[0] * pt[1] + c[3] * pt[0] + c[4] * pt[1] + c[5] - pt[2]
+    assert abs(e1[0]) > 0.3 and np.abs(e1[60:]).max() < 0.12 and abs(e1[-1]) < 0.06
+    assert abs(pt[0, -1] - cfg["px_ref"]) < 0.05
+    # log conventions: u[:,0] = qdot_0, z[:,0] = [q0;qdot0]
+    np.testing.assert_array_equal(o["u"][:, 0], cfg["qdot0"])
+    np.testing.assert_array_equal(o["z"][:, 0], np.concatenate([cfg["q0"], cfg["qdot0"]]))
+    assert np.all(o["u"] <= cfg["umax"][:, None] + 1e-7) and np.all(o["u"] >= cfg["umin"][:, None] - 1e-7)
+    if stype == "SQP_RTI":
+        assert (o["sqp_iter"] == 1).all()
+
+
+def test_rti_and_sqp_agree_in_steady_state(orc, ur10_rb):
+    """A.6: both converge to the same NLP solution once the transient is over."""
+    kw = dict(prediction_horizon=10, simulation_time=3)
+    a = orc.run(ur10_rb, orc.make_params(_cfg(solver_options={"nlp_solver_type": "SQP_RTI"}, **kw)))
+    b = orc.run(ur10_rb, orc.make_params(_cfg(solver_options={"nlp_solver_type": "SQP"}, **kw)))
+    np.testing.assert_allclose(a["u"][:, -20:], b["u"][:, -20:], atol=5e-2)
+    np.testing.assert_allclose(a["z"][:6, -1], b["z"][:6, -1], atol=5e-2)
