@@ -1,0 +1,136 @@
+/*
+ * mpcbatch.h -- C ABI of libmpcbatch.so, the MI355X-native batched MPC rollout engine.
+ *
+ * Drop-in boundary for the hot path of lynet55/robotic-mpc:
+ *     SimulationManager.run_all -> Simulator.__init__ / Simulator.run
+ *     (simulator.py:641-676, 18-127, 199-241)
+ * i.e. everything the reference does through acados_template's ctypes binding to its
+ * per-instance generated libacados_ocp_solver_<model>.so:
+ *     AcadosOcpSolver(ocp, json_file)            trajectory_optimizer.py:183-186
+ *     solver.set(0,'lbx'|'ubx',x)                simulator.py:210-211
+ *     solver.solve()                             simulator.py:212
+ *     solver.get(0,'u')                          simulator.py:213
+ *     solver.get_stats('sqp_iter'|'time_tot')    simulator.py:218,220
+ *     solver.get_residuals(), get_cost()         simulator.py:219,221
+ * plus the plant step and logging of simulation_model.Robot.update
+ * (simulation_model.py:85-91).  Where the reference builds and drives ONE solver per
+ * simulation, this ABI takes a BATCH of simulations (one 64-double parameter record each)
+ * and runs all closed loops on the GPU, one wavefront per simulation.
+ *
+ * Conventions: plain C, no exceptions; every function returns 0 on success or a negative
+ * MPCB_E* code, with text in mpcb_last_error(); the caller owns every buffer it passes;
+ * a handle is bound to one device and is not thread-safe; per-simulation solver failures
+ * are DATA (status arrays, acados codes 0/1/2/3/4), never call failures.
+ * There is no CPU fallback: without a HIP device mpcb_create fails.
+ */
+#ifndef MPCBATCH_H
+#define MPCBATCH_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCB_VERSION 100      /* 0.1.0 */
+#define MPCB_NPARAM 64        /* doubles per simulation, layout below */
+#define MPCB_NROBOT 105       /* doubles of kinematic constants, layout below */
+
+#define MPCB_OK 0
+#define MPCB_EINVAL (-1)      /* bad argument / inconsistent sizes */
+#define MPCB_ENODEV (-2)      /* no usable HIP device */
+#define MPCB_ENOMEM (-3)      /* device allocation failed */
+#define MPCB_EHIP (-4)        /* HIP runtime error, see mpcb_last_error */
+#define MPCB_ESTATE (-5)      /* call order violated (e.g. rollout before setup) */
+
+#define MPCB_SOLVER_SQP 0     /* trajectory_optimizer.py:60 (default) */
+#define MPCB_SOLVER_SQP_RTI 1 /* solver_options {'nlp_solver_type': 'SQP_RTI'} */
+
+typedef struct mpcb_handle mpcb_handle;
+
+/* Batch-uniform part of the configuration (one launch = one bucket of simulations that
+ * share these). Mirrors Simulator.__init__ / MPC.__init__ arguments as noted. */
+typedef struct {
+    int batch;        /* number of simulations in this call                               */
+    int N;            /* prediction_horizon (simulator.py:42)                             */
+    int Nsim;         /* int(simulation_time/dt) (simulator.py:41)                        */
+    int solver_type;  /* MPCB_SOLVER_*                                                    */
+    int max_iter;     /* nlp_solver_max_iter (trajectory_optimizer.py:67)                 */
+    int qp_iter_max;  /* acados qp_solver_iter_max (default 50)                           */
+    int fixed_step;   /* 1: globalization FIXED_STEP, 0: MERIT_BACKTRACKING (:68)         */
+    int reserved;
+} mpcb_problem;
+
+/* Per-simulation parameter record, MPCB_NPARAM doubles (simulator.py:18-35):
+ *   [0] dt  [1] tol (acados nlp tol, 1e-6)  [2] qp_tol (trajectory_optimizer.py:63)
+ *   [3] w_u [4] w_qddot [5] px_ref [6] vy_ref [7] reserved
+ *   [8..13] wcv   [14..19] q_0   [20..25] qdot_0   [26..31] q_min   [32..37] q_max
+ *   [38..43] qdot_min (lbu)   [44..49] qdot_max (ubu)
+ *   [50..55] surface_coeffs a,b,c,d,e,f (surface.py:14-17)
+ *   [56..60] task weights (trajectory_optimizer.py:44-48, all 50.0)   [61..63] reserved
+ * Bounds with |value| >= 1e29 are treated as absent.
+ *
+ * Kinematic constants, MPCB_NROBOT doubles (what loader.py:24-36 extracts from the URDF):
+ *   [0..83]  7 placements [R row-major (9); p (3)]: joint i in its parent at q=0, i=0..5,
+ *            then the end-effector frame in the last link
+ *   [84..101] 6 unit joint axes   [102..104] translation_ee_t (prediction_model.py:9)
+ */
+
+/* Result logs, batch-major; per simulation the shapes of the reference's own logs
+ * (simulation_model.py:25-29, simulator.py:59-65).  T1 = Nsim+1. */
+typedef struct {
+    double *z;           /* [batch][12][T1]  q;qdot                      */
+    double *u;           /* [batch][6][T1]   u[:,0]=qdot_0, u[:,i+1]=u_i */
+    double *ee_pose;     /* [batch][12][T1]  p; R row-major              */
+    double *ee_rpy;      /* [batch][3][T1]                               */
+    double *ee_vel;      /* [batch][6][T1]   J_world * qdot              */
+    int *status;         /* [batch][Nsim]    acados status 0/1/2/3/4     */
+    int *sqp_iter;       /* [batch][Nsim]                                */
+    int *qp_iter;        /* [batch][Nsim]    interior-point iterations   */
+    double *residuals;   /* [batch][Nsim][4] stat, eq, ineq, comp        */
+    double *cost;        /* [batch][Nsim]                                */
+    double *solver_time; /* [batch][Nsim]    seconds on the device       */
+} mpcb_result;
+
+int mpcb_version(void);
+/* Number of HIP devices visible; 0 when none (never an error by itself). */
+int mpcb_device_count(void);
+
+/* Create a handle on `device` (>= 0).  Fails with MPCB_ENODEV when no GPU is usable. */
+int mpcb_create(mpcb_handle **h, int device);
+void mpcb_destroy(mpcb_handle *h);
+const char *mpcb_last_error(const mpcb_handle *h);
+
+/* Bytes of device workspace mpcb_setup will hold for `p`. */
+size_t mpcb_workspace_bytes(const mpcb_problem *p);
+/* Bytes of one simulation's result logs (sum over the mpcb_result arrays). */
+size_t mpcb_result_bytes_per_sim(const mpcb_problem *p);
+
+/* Replaces Simulator.__init__ + MPC.finalize_solver for the whole batch: packs the
+ * parameter records (host pointers), uploads them, sizes the workspace.  No code generation. */
+int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host);
+
+/* Replaces the Simulator.run loop for closed-loop steps [step0, step1) of every simulation.
+ * `out_dev` holds DEVICE pointers (caller-allocated, e.g. torch tensors); `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous; step0 must continue where the previous
+ * call stopped (0 first). */
+int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *out_dev, void *stream);
+
+/* Wait for the stream of the last rollout. */
+int mpcb_sync(mpcb_handle *h);
+
+/* Device time of the last mpcb_rollout launch, measured with HIP events on its stream (ms). */
+int mpcb_last_kernel_ms(mpcb_handle *h, float *ms);
+
+/* Static resources of the rollout kernel: VGPRs, SGPRs(0 if unknown), LDS bytes, scratch bytes. */
+int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
+
+/* Convenience for callers without device buffers of their own: setup + rollout(0,Nsim) +
+ * copy-back into HOST arrays `out_host`. */
+int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host,
+             const mpcb_result *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCBATCH_H */

@@ -1,0 +1,313 @@
+// mpc_kernel.hip -- gfx950 kernel + C ABI (include/mpcbatch.h) of the batched MPC engine.
+//
+// Launch geometry: one 64-thread workgroup (= one wavefront) per simulation instance, grid =
+// batch.  A wave is never split across phases, so the phase separator is a wavefront-scope
+// fence + wave barrier: no s_barrier, no forced vmcnt(0) -- a single wave issues its LDS and
+// vector-memory instructions in order, which is all the bulk-synchronous phases need.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcbatch.h"
+#include "mpc_core.h"
+#include "mpc_pack.h"
+
+using namespace mpcb;
+
+static_assert(sizeof(mpcb_problem) == sizeof(Problem), "ABI struct mismatch");
+static_assert(sizeof(mpcb_result) == sizeof(Outputs), "ABI struct mismatch");
+static_assert(sizeof(Robot) == MPCB_NROBOT * sizeof(double), "robot layout");
+
+struct DevExec {
+    int lane;
+    template <class F>
+    __device__ __forceinline__ void par(F &&f)
+    {
+        f(lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ double reduce_sum(const double *r)
+    {
+        double v = r[lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ __forceinline__ double reduce_max(const double *r)
+    {
+        double v = r[lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        return v;
+    }
+    __device__ __forceinline__ double reduce_min(const double *r)
+    {
+        double v = r[lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+        return v;
+    }
+    // constant 100 MHz counter (s_memrealtime)
+    __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
+};
+
+__global__ __launch_bounds__(WAVE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+                                                           double *ws_base, size_t ws_stride, Outputs out, int step0,
+                                                           int step1)
+{
+    __shared__ Smem sm;
+    const int inst = blockIdx.x;
+    if (inst >= pb.batch) return;
+    DevExec ex{(int)threadIdx.x};
+    Ctx c{&pb, &rb, params + inst, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), &sm, pb.N};
+    Engine<DevExec> eng(ex, c);
+    eng.rollout(out, inst, step0, step1);
+}
+
+// ------------------------------------------------------------------------------------ host
+struct mpcb_handle {
+    int device = -1;
+    std::string err;
+    Problem pb{};
+    Robot rb{};
+    bool ready = false;
+    int next_step = 0;
+    InstParams *d_params = nullptr;
+    size_t params_cap = 0;
+    double *d_ws = nullptr;
+    size_t ws_cap = 0;
+    size_t ws_stride = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool timed = false;
+};
+
+static int fail(mpcb_handle *h, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+#define HIPCHK(h, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail((h), MPCB_EHIP, #call, e_);      \
+    } while (0)
+
+static int check_problem(mpcb_handle *h, const mpcb_problem *p)
+{
+    if (!p) return fail(h, MPCB_EINVAL, "problem is NULL");
+    if (p->batch < 1) return fail(h, MPCB_EINVAL, "batch must be >= 1");
+    if (p->N < 1 || p->N > 4096) return fail(h, MPCB_EINVAL, "prediction horizon N out of range [1,4096]");
+    if (p->Nsim < 1) return fail(h, MPCB_EINVAL, "Nsim must be >= 1");
+    if (p->solver_type != MPCB_SOLVER_SQP && p->solver_type != MPCB_SOLVER_SQP_RTI)
+        return fail(h, MPCB_EINVAL, "solver_type must be MPCB_SOLVER_SQP or MPCB_SOLVER_SQP_RTI");
+    if (p->max_iter < 1 || p->qp_iter_max < 1) return fail(h, MPCB_EINVAL, "iteration limits must be >= 1");
+    return MPCB_OK;
+}
+
+extern "C" {
+
+int mpcb_version(void) { return MPCB_VERSION; }
+
+int mpcb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mpcb_create(mpcb_handle **out, int device)
+{
+    if (!out) return MPCB_EINVAL;
+    *out = nullptr;
+    int n = mpcb_device_count();
+    if (n <= 0 || device < 0 || device >= n) return MPCB_ENODEV;
+    mpcb_handle *h = new (std::nothrow) mpcb_handle;
+    if (!h) return MPCB_ENOMEM;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+        hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return MPCB_EHIP;
+    }
+    *out = h;
+    return MPCB_OK;
+}
+
+void mpcb_destroy(mpcb_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+const char *mpcb_last_error(const mpcb_handle *h) { return h ? h->err.c_str() : "invalid handle"; }
+
+size_t mpcb_workspace_bytes(const mpcb_problem *p)
+{
+    if (!p || p->N < 1 || p->batch < 1) return 0;
+    return (size_t)p->batch * ws_doubles_per_instance(p->N) * sizeof(double);
+}
+
+size_t mpcb_result_bytes_per_sim(const mpcb_problem *p)
+{
+    if (!p) return 0;
+    const size_t T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
+    return (12 + 6 + 12 + 3 + 6) * T1 * sizeof(double) + 3 * S * sizeof(int) + (4 + 1 + 1) * S * sizeof(double);
+}
+
+int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host)
+{
+    if (!h) return MPCB_EINVAL;
+    int rc = check_problem(h, p);
+    if (rc) return rc;
+    if (!params_host || !robot_host) return fail(h, MPCB_EINVAL, "params/robot pointer is NULL");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<InstParams> packed((size_t)p->batch);
+    for (int i = 0; i < p->batch; i++) {
+        const double *pp = params_host + (size_t)i * MPCB_NPARAM;
+        if (!(pp[0] > 0.0)) return fail(h, MPCB_EINVAL, "dt must be positive");
+        for (int j = 0; j < 6; j++)
+            if (!(pp[8 + j] > 0.0)) return fail(h, MPCB_EINVAL, "wcv must be positive");
+        for (int j = 0; j < MPCB_NPARAM; j++)
+            if (std::isnan(pp[j])) return fail(h, MPCB_EINVAL, "NaN in parameter record");
+        pack_inst_params(pp, &packed[(size_t)i]);
+    }
+    std::memcpy(&h->rb, robot_host, sizeof(Robot));
+    std::memcpy(&h->pb, p, sizeof(Problem));
+    const size_t pbytes = packed.size() * sizeof(InstParams);
+    if (pbytes > h->params_cap) {
+        if (h->d_params) (void)hipFree(h->d_params);
+        h->d_params = nullptr; h->params_cap = 0;
+        if (hipMalloc((void **)&h->d_params, pbytes) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(params)");
+        h->params_cap = pbytes;
+    }
+    HIPCHK(h, hipMemcpy(h->d_params, packed.data(), pbytes, hipMemcpyHostToDevice));
+    h->ws_stride = ws_doubles_per_instance(p->N);
+    const size_t wbytes = mpcb_workspace_bytes(p);
+    if (wbytes > h->ws_cap) {
+        if (h->d_ws) (void)hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_cap = 0;
+        if (hipMalloc((void **)&h->d_ws, wbytes) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(workspace)");
+        h->ws_cap = wbytes;
+    }
+    h->ready = true;
+    h->next_step = 0;
+    h->timed = false;
+    return MPCB_OK;
+}
+
+int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, void *stream)
+{
+    if (!h) return MPCB_EINVAL;
+    if (!h->ready) return fail(h, MPCB_ESTATE, "mpcb_rollout before mpcb_setup");
+    if (!o) return fail(h, MPCB_EINVAL, "result pointer is NULL");
+    if (step0 != h->next_step) return fail(h, MPCB_ESTATE, "step0 does not continue the previous rollout");
+    if (step1 <= step0 || step1 > h->pb.Nsim) return fail(h, MPCB_EINVAL, "step range out of bounds");
+    if (!o->z || !o->u || !o->ee_pose || !o->ee_rpy || !o->ee_vel || !o->status || !o->sqp_iter || !o->qp_iter ||
+        !o->residuals || !o->cost || !o->solver_time)
+        return fail(h, MPCB_EINVAL, "every result array must be provided");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Outputs out;
+    std::memcpy(&out, o, sizeof out);
+    HIPCHK(h, hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(mpc_rollout_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), 0, s, h->pb, h->rb, h->d_params,
+                       h->d_ws, h->ws_stride, out, step0, step1);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, s));
+    h->last_stream = s;
+    h->timed = true;
+    h->next_step = step1;
+    return MPCB_OK;
+}
+
+int mpcb_sync(mpcb_handle *h)
+{
+    if (!h) return MPCB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    return MPCB_OK;
+}
+
+int mpcb_last_kernel_ms(mpcb_handle *h, float *ms)
+{
+    if (!h || !ms) return MPCB_EINVAL;
+    if (!h->timed) return fail(h, MPCB_ESTATE, "no rollout has been launched");
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MPCB_OK;
+}
+
+int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes)
+{
+    if (!h) return MPCB_EINVAL;
+    hipFuncAttributes a;
+    HIPCHK(h, hipFuncGetAttributes(&a, (const void *)mpc_rollout_kernel));
+    if (vgprs) *vgprs = a.numRegs;
+    if (sgprs) *sgprs = 0;
+    if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
+    if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+    return MPCB_OK;
+}
+
+int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host,
+             const mpcb_result *oh)
+{
+    if (!h) return MPCB_EINVAL;
+    if (!oh) return fail(h, MPCB_EINVAL, "result pointer is NULL");
+    int rc = mpcb_setup(h, p, params_host, robot_host);
+    if (rc) return rc;
+    const size_t B = (size_t)p->batch, T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
+    const size_t nd[5] = {12 * T1, 6 * T1, 12 * T1, 3 * T1, 6 * T1};
+    const size_t dbl_total = B * (nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + 6 * S);
+    const size_t int_total = B * 3 * S;
+    double *dd = nullptr;
+    int *di = nullptr;
+    if (hipMalloc((void **)&dd, dbl_total * sizeof(double)) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(results)");
+    if (hipMalloc((void **)&di, int_total * sizeof(int)) != hipSuccess) { (void)hipFree(dd); return fail(h, MPCB_ENOMEM, "hipMalloc(results)"); }
+    mpcb_result od;
+    double *pd = dd;
+    od.z = pd; pd += B * nd[0];
+    od.u = pd; pd += B * nd[1];
+    od.ee_pose = pd; pd += B * nd[2];
+    od.ee_rpy = pd; pd += B * nd[3];
+    od.ee_vel = pd; pd += B * nd[4];
+    od.residuals = pd; pd += B * 4 * S;
+    od.cost = pd; pd += B * S;
+    od.solver_time = pd; pd += B * S;
+    od.status = di; od.sqp_iter = di + B * S; od.qp_iter = di + 2 * B * S;
+    rc = mpcb_rollout(h, 0, p->Nsim, &od, nullptr);
+    if (rc == MPCB_OK) rc = mpcb_sync(h);
+    if (rc == MPCB_OK) {
+        struct { void *dst; const void *src; size_t n; } cp[] = {
+            {oh->z, od.z, B * nd[0] * 8}, {oh->u, od.u, B * nd[1] * 8}, {oh->ee_pose, od.ee_pose, B * nd[2] * 8},
+            {oh->ee_rpy, od.ee_rpy, B * nd[3] * 8}, {oh->ee_vel, od.ee_vel, B * nd[4] * 8},
+            {oh->residuals, od.residuals, B * 4 * S * 8}, {oh->cost, od.cost, B * S * 8},
+            {oh->solver_time, od.solver_time, B * S * 8}, {oh->status, od.status, B * S * 4},
+            {oh->sqp_iter, od.sqp_iter, B * S * 4}, {oh->qp_iter, od.qp_iter, B * S * 4}};
+        for (auto &c : cp) {
+            if (!c.dst) continue;
+            hipError_t e = hipMemcpy(c.dst, c.src, c.n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail(h, MPCB_EHIP, "hipMemcpy(results)", e); break; }
+        }
+    }
+    (void)hipFree(dd);
+    (void)hipFree(di);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+"""Packing of resolved configs into the flat fp64 records the C-ABI takes
+(layout documented in csrc/mpc_pack.h and include/mpcbatch.h)."""
+from __future__ import annotations
+
+from typing import Dict, Sequence
+
+import numpy as np
+
+NPARAM = 64
+
+
+def pack_params(cfg: Dict) -> np.ndarray:
+    """One instance: resolved config (config.resolve_config) -> 64 doubles."""
+    p = np.zeros(NPARAM, dtype=np.float64)
+    p[0] = cfg["dt"]; p[1] = cfg["tol"]; p[2] = cfg["qp_tol"]; p[3] = cfg["w_u"]; p[4] = cfg["w_qddot"]
+    p[5] = cfg["px_ref"]; p[6] = cfg["vy_ref"]
+    p[8:14] = cfg["wcv"]; p[14:20] = cfg["q0"]; p[20:26] = cfg["qdot0"]
+    p[26:32] = cfg["qmin"]; p[32:38] = cfg["qmax"]; p[38:44] = cfg["umin"]; p[44:50] = cfg["umax"]
+    p[50:56] = cfg["coeffs"]; p[56:61] = cfg["w_task"]
+    return p
+
+
+def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
+    return np.ascontiguousarray(np.stack([pack_params(c) for c in cfgs]))
+
+
+def bucket_key(cfg: Dict):
+    """Instances that can share one launch: same horizon/steps/solver options and robot."""
+    return (cfg["robot_name"], cfg.get("urdf_path"), cfg.get("ee_frame"), tuple(np.asarray(cfg["t_ee"]).tolist()),
+            cfg["N"], cfg["Nsim"], cfg["solver_type"], cfg["max_iter"], cfg["qp_iter_max"], bool(cfg["fixed_step"]))

@@ -1,0 +1,56 @@
+// emu_harness.cpp -- TEST-ONLY host emulation of the wave-cooperative engine.
+//
+// Instantiates robotic-mpc_amd/csrc/mpc_core.h with an executor that runs the 64 lanes of
+// every bulk-synchronous phase one after the other on the CPU.  Purpose: debug the product's
+// device code (lane mappings, phase hazards, algebra) against the oracle in a container
+// that has no GPU.  It is compiled host-only (hipcc --offload-host-only), is loaded only by
+// tests/test_emulation.py, and is NOT linked into libmpcbatch.so: the product has no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../robotic-mpc_amd/csrc/mpc_core.h"
+#include "../../robotic-mpc_amd/csrc/mpc_pack.h"
+
+using namespace mpcb;
+
+struct HostExec {
+    template <class F>
+    void par(F &&f)
+    {
+        for (int l = 0; l < WAVE; l++) f(l);
+    }
+    double reduce_sum(const double *r) { double s = 0; for (int l = 0; l < WAVE; l++) s += r[l]; return s; }
+    double reduce_max(const double *r) { double s = r[0]; for (int l = 1; l < WAVE; l++) s = fmax(s, r[l]); return s; }
+    double reduce_min(const double *r) { double s = r[0]; for (int l = 1; l < WAVE; l++) s = fmin(s, r[l]); return s; }
+    double clock() { return 0.0; }
+};
+
+extern "C" int emu_run(const Problem *pb, const double *robot105, const double *params /* [batch][MPCB_NPARAM] */,
+                       double *z, double *u, double *ee_pose, double *ee_rpy, double *ee_vel, int *status,
+                       int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time,
+                       int step_chunk)
+{
+    Robot rb;
+    std::memcpy(&rb, robot105, sizeof(Robot));
+    Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time};
+    const size_t wsd = ws_doubles_per_instance(pb->N);
+    std::vector<double> ws(wsd);
+    for (int inst = 0; inst < pb->batch; inst++) {
+        InstParams P;
+        pack_inst_params(params + (size_t)inst * MPCB_NPARAM, &P);
+        Smem sm;
+        std::memset(&sm, 0, sizeof sm);
+        HostExec ex;
+        if (step_chunk <= 0) step_chunk = pb->Nsim;
+        for (int s0 = 0; s0 < pb->Nsim; s0 += step_chunk) {
+            Ctx c{pb, &rb, &P, ws_carve(ws.data(), pb->N), &sm, pb->N};
+            Engine<HostExec> eng(ex, c);
+            const int s1 = s0 + step_chunk < pb->Nsim ? s0 + step_chunk : pb->Nsim;
+            eng.rollout(out, inst, s0, s1);
+        }
+    }
+    return 0;
+}
