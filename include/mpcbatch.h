@@ -113,7 +113,7 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
 /* Replaces the Simulator.run loop for closed-loop steps [step0, step1) of every simulation.
  * `out_dev` holds DEVICE pointers (caller-allocated, e.g. torch tensors); `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous; step0 must continue where the previous
- * call stopped (0 first). */
+ * call stopped, or be 0, which restarts every simulation from its initial state. */
 int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *out_dev, void *stream);
 
 /* Wait for the stream of the last rollout. */

@@ -25,6 +25,12 @@ static_assert(sizeof(Robot) == MPCB_NROBOT * sizeof(double), "robot layout");
 
 struct DevExec {
     int lane;
+    // per-lane registers that live across phases (prefetched stage records)
+    template <class T>
+    struct PerLane {
+        T v;
+        __device__ __forceinline__ T &at(int) { return v; }
+    };
     template <class F>
     __device__ __forceinline__ void par(F &&f)
     {
@@ -65,7 +71,8 @@ __global__ __launch_bounds__(WAVE) void mpc_rollout_kernel(Problem pb, Robot rb,
     const int inst = blockIdx.x;
     if (inst >= pb.batch) return;
     DevExec ex{(int)threadIdx.x};
-    Ctx c{&pb, &rb, params + inst, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), &sm, pb.N};
+    load_constants(ex, sm, params + inst, &rb);
+    Ctx c{&pb, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), &sm, pb.N};
     Engine<DevExec> eng(ex, c);
     eng.rollout(out, inst, step0, step1);
 }
@@ -215,7 +222,8 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     if (!h) return MPCB_EINVAL;
     if (!h->ready) return fail(h, MPCB_ESTATE, "mpcb_rollout before mpcb_setup");
     if (!o) return fail(h, MPCB_EINVAL, "result pointer is NULL");
-    if (step0 != h->next_step) return fail(h, MPCB_ESTATE, "step0 does not continue the previous rollout");
+    if (step0 != h->next_step && step0 != 0)
+        return fail(h, MPCB_ESTATE, "step0 must continue the previous rollout (or be 0 to restart)");
     if (step1 <= step0 || step1 > h->pb.Nsim) return fail(h, MPCB_EINVAL, "step range out of bounds");
     if (!o->z || !o->u || !o->ee_pose || !o->ee_rpy || !o->ee_vel || !o->status || !o->sqp_iter || !o->qp_iter ||
         !o->residuals || !o->cost || !o->solver_time)
@@ -261,6 +269,17 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
     if (sgprs) *sgprs = 0;
     if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
     if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+    return MPCB_OK;
+}
+
+// Diagnostic builds only (-DMPCB_PROFILE): per-section device seconds accumulated by instance
+// `inst`; all zeros in the product build.  Not part of include/mpcbatch.h.
+int mpcb_debug_profile(mpcb_handle *h, int inst, double *out16)
+{
+    if (!h || !out16 || !h->ready || inst < 0 || inst >= h->pb.batch) return MPCB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const double *src = h->d_ws + (size_t)inst * h->ws_stride + (size_t)(h->pb.N + 1) * STAGE_DOUBLES + 32;
+    HIPCHK(h, hipMemcpy(out16, src, NPROF * sizeof(double), hipMemcpyDeviceToHost));
     return MPCB_OK;
 }
 

@@ -84,10 +84,10 @@ MPC_HD void kin_eval(const Robot &rb, const double *q, Kin &k)
 }
 
 // Task functions g1..g5 minus their references (trajectory_optimizer.py:109-126), and, when
-// JAC, the Jacobian rows wrt q (5x6) and d g5 / d qdot (6).  Output goes straight into a
-// LIN record: lin[0..4] = r, lin[5..34] = Gq, lin[35..40] = gv5.
+// JAC, the Jacobian rows wrt q (5x6) and d g5 / d qdot (6).  Output goes straight into the
+// stage records: lin[LIN_R..] = r, ric[RIC_GQ..] = Gq, ric[RIC_GV..] = gv5.
 template <bool JAC>
-MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *lin)
+MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *lin, double *ric)
 {
     Kin k;
     kin_eval(rb, q, k);
@@ -124,11 +124,11 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         const V3 zi = k.z[i];
         const V3 dpt = cross(zi, pt - k.o[i]);
         const V3 dzh = cross(zi, zh), dyh = cross(zi, yh), dtw = cross(zi, tw);
-        lin[LIN_GQ + 0 * 6 + i] = Sx * dpt.x + Sy * dpt.y - dpt.z;
+        ric[RIC_GQ + 0 * 6 + i] = Sx * dpt.x + Sy * dpt.y - dpt.z;
         const V3 dn = dpt.x * nX + dpt.y * nY;
-        lin[LIN_GQ + 1 * 6 + i] = dot(dn, zh) + dot(n, dzh);
-        lin[LIN_GQ + 2 * 6 + i] = dyh.x;
-        lin[LIN_GQ + 3 * 6 + i] = dpt.x;
+        ric[RIC_GQ + 1 * 6 + i] = dot(dn, zh) + dot(n, dzh);
+        ric[RIC_GQ + 2 * 6 + i] = dyh.x;
+        ric[RIC_GQ + 3 * 6 + i] = dpt.x;
         V3 dvl = v3(0, 0, 0), otail = v3(0, 0, 0);
 #pragma unroll
         for (int j = i + 1; j < 6; j++) {
@@ -139,8 +139,8 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         }
         const V3 dom = cross(zi, otail);
         const V3 ds = dvl + cross(dom, tw) + cross(om, dtw);
-        lin[LIN_GQ + 4 * 6 + i] = dot(dyh, s) + dot(yh, ds);
-        lin[LIN_GV + i] = dot(yh, cj[i] + cross(zi, tw));
+        ric[RIC_GQ + 4 * 6 + i] = dot(dyh, s) + dot(yh, ds);
+        ric[RIC_GV + i] = dot(yh, cj[i] + cross(zi, tw));
     }
 }
 

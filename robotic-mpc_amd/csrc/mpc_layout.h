@@ -31,29 +31,28 @@ constexpr int W_QW = 18;    // QP primal [du; dq; dqdot]
 constexpr int W_PI = 12;
 constexpr int W_LAM = 24;
 constexpr int W_T = 24;
-constexpr int W_LIN = 48;   // [0..4] r=g-gref, [5..34] Gq (5x6), [35..40] gv5, [41..45] y, pad
+constexpr int W_LIN = 16;   // [0..4] r = g - gref, [5..9] y = W (r + G delta), pad
+constexpr int W_RIC = 80;   // everything the factorisation sweep reads for one stage, contiguous:
+                            // [0..29] Gq (5x6), [30..35] gv5, [36..47] Gamma, [48..65] gt, [66..77] rb
 constexpr int W_BD = 12;    // dynamics defect of the NLP iterate
 constexpr int W_RG = 18;
-constexpr int W_RB = 12;
 constexpr int W_RD = 24;
 constexpr int W_RM = 24;
 constexpr int W_DW = 18;
 constexpr int W_DPI = 12;
 constexpr int W_DLAM = 24;
 constexpr int W_DT = 24;
-constexpr int W_GAM = 12;
-constexpr int W_GT = 18;
-constexpr int W_HU = 6;
-constexpr int W_FAC = 112;  // Kfb (6x12 row-major) = R^-1 S, Rinv (6x6), pad 4
+constexpr int W_FAC = 128;  // what the solve sweeps read for one stage, contiguous:
+                            // [0..71] Kfb = R^-1 S (6x12), [72..107] R^-1 (6x6), [108..113] h_u, [114..125] p_k
 constexpr int W_PM = 144;   // cost-to-go matrix P_k (12x12, full)
-constexpr int W_PV = 12;    // cost-to-go vector p_k
 constexpr int W_MW = 36;    // merit weights: dyn (12) + ineq (24)    (SQP only)
 
-constexpr int LIN_R = 0, LIN_GQ = 5, LIN_GV = 35, LIN_Y = 41;
-constexpr int FAC_K = 0, FAC_RI = 72;
+constexpr int LIN_R = 0, LIN_Y = 5;
+constexpr int RIC_GQ = 0, RIC_GV = 30, RIC_GAM = 36, RIC_GT = 48, RIC_RB = 66;
+constexpr int FAC_K = 0, FAC_RI = 72, FAC_HU = 108, FAC_PV = 114;
 
-constexpr int STAGE_DOUBLES = W_X + W_U + W_QW + W_PI + W_LAM + W_T + W_LIN + W_BD + W_RG + W_RB + W_RD + W_RM +
-                              W_DW + W_DPI + W_DLAM + W_DT + W_GAM + W_GT + W_HU + W_FAC + W_PM + W_PV +
+constexpr int STAGE_DOUBLES = W_X + W_U + W_QW + W_PI + W_LAM + W_T + W_LIN + W_RIC + W_BD + W_RG + W_RD + W_RM +
+                              W_DW + W_DPI + W_DLAM + W_DT + W_FAC + W_PM +
                               /* NLP multipliers + trial iterate + merit weights (SQP) */
                               W_PI + W_LAM + W_T + W_X + W_U + W_MW;
 
@@ -106,13 +105,15 @@ struct Outputs {
 
 // Views into one instance's workspace.
 struct Ws {
-    double *X, *U, *QW, *QPI, *QLAM, *QT, *LIN, *BD, *RG, *RB, *RD, *RM, *DW, *DPI, *DLAM, *DT, *GAM, *GT, *HU,
-        *FAC, *PM, *PV;
+    double *X, *U, *QW, *QPI, *QLAM, *QT, *LIN, *RIC, *BD, *RG, *RD, *RM, *DW, *DPI, *DLAM, *DT, *FAC, *PM;
     double *NPI, *NLAM, *NT, *TX, *TU, *MW;  // SQP extras
     double *state;                           // persistent scalars between launches
 };
 
-constexpr int STATE_DOUBLES = 64;  // [0..11] plant state z, [12] first_call flag, [13..24] mw_x0, ...
+// [0..11] plant state z, [12] cost of the held linearisation, [13..24] merit weights of the
+// x0 constraint, [25] linearisation-valid flag, [32..47] profile counters (diagnostic build)
+constexpr int STATE_DOUBLES = 64;
+constexpr int NPROF = 16;
 
 MPC_HD size_t ws_doubles_per_instance(int N)
 {
@@ -131,21 +132,17 @@ MPC_HD Ws ws_carve(double *base, int N)
     w.QLAM = p; p += n1 * W_LAM;
     w.QT = p; p += n1 * W_T;
     w.LIN = p; p += n1 * W_LIN;
+    w.RIC = p; p += n1 * W_RIC;
     w.BD = p; p += n1 * W_BD;
     w.RG = p; p += n1 * W_RG;
-    w.RB = p; p += n1 * W_RB;
     w.RD = p; p += n1 * W_RD;
     w.RM = p; p += n1 * W_RM;
     w.DW = p; p += n1 * W_DW;
     w.DPI = p; p += n1 * W_DPI;
     w.DLAM = p; p += n1 * W_DLAM;
     w.DT = p; p += n1 * W_DT;
-    w.GAM = p; p += n1 * W_GAM;
-    w.GT = p; p += n1 * W_GT;
-    w.HU = p; p += n1 * W_HU;
     w.FAC = p; p += n1 * W_FAC;
     w.PM = p; p += n1 * W_PM;
-    w.PV = p; p += n1 * W_PV;
     w.NPI = p; p += n1 * W_PI;
     w.NLAM = p; p += n1 * W_LAM;
     w.NT = p; p += n1 * W_T;
@@ -157,7 +154,11 @@ MPC_HD Ws ws_carve(double *base, int N)
 }
 
 // LDS working set of one wavefront (one instance).
+constexpr int STG_DOUBLES = 2 * 288;  // two staging buffers
 struct Smem {
+    InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
+    Robot rb;
+    double stg[STG_DOUBLES];  // stage record prefetched from HBM one stage ahead of the sweeps
     double M[2][144];   // P_{k+1} / P_k double buffer during the factorisation sweep
     double pv[2][12];
     double Rt[36];      // R~ = H_uu + Gamma_u + B'MB

@@ -17,6 +17,11 @@
 using namespace mpcb;
 
 struct HostExec {
+    template <class T>
+    struct PerLane {
+        T v[WAVE];
+        T &at(int l) { return v[l]; }
+    };
     template <class F>
     void par(F &&f)
     {
@@ -46,7 +51,8 @@ extern "C" int emu_run(const Problem *pb, const double *robot105, const double *
         HostExec ex;
         if (step_chunk <= 0) step_chunk = pb->Nsim;
         for (int s0 = 0; s0 < pb->Nsim; s0 += step_chunk) {
-            Ctx c{pb, &rb, &P, ws_carve(ws.data(), pb->N), &sm, pb->N};
+            load_constants(ex, sm, &P, &rb);
+            Ctx c{pb, ws_carve(ws.data(), pb->N), &sm, pb->N};
             Engine<HostExec> eng(ex, c);
             const int s1 = s0 + step_chunk < pb->Nsim ? s0 + step_chunk : pb->Nsim;
             eng.rollout(out, inst, s0, s1);

@@ -135,3 +135,48 @@ def random_ocp_qp(rng, N, wcv=200.0, Ts=0.01, scale_g=1.0, tight=False):
     g[N] = 0
     dx0 = rng.normal(size=12) * (1e-3 if tight else 1e-2)
     return H, g, b, A, B, lb, ub, dx0
+
+
+def oracle_runner(cfgs, chain):
+    """A SimulationManager runner backed by the CPU oracle (tests only): lets the host layer
+    (queueing, bucketing, sharding, gather, analysis) be exercised without a GPU."""
+    from oracle import orc
+
+    rb = orc.make_robot(chain, cfgs[0]["t_ee"]) if cfgs else None
+    recs = [orc.run(rb, orc.make_params(c)) for c in cfgs]
+    keys = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "status", "sqp_iter", "qp_iter", "residuals", "cost", "solver_time")
+    return {k: np.stack([r[k] for r in recs]) for k in keys}
+
+
+def reference_errors_loop(ee_pose, ee_vel, coeffs, t_ee, px_ref, vy_ref):
+    """simulator.py:280-344 restated literally (per-step loop, numpy ops as written there)."""
+    p_ee_all = ee_pose[:3, :]
+    R_flat_all = ee_pose[3:12, :]
+    n_steps = p_ee_all.shape[1]
+    e = {k: np.zeros(n_steps) for k in ("e1", "e2", "e3", "e4", "e5", "p_task_z")}
+    a, b, c, d, ee, f = coeffs
+    R_ee_t = np.eye(3)
+    t_ee = np.asarray(t_ee).reshape(3,)
+    for i in range(n_steps):
+        p_ee = p_ee_all[:, i]
+        R_w_ee = R_flat_all[:, i].reshape(3, 3)
+        vee = ee_vel[:, i]
+        v_ee_w, w_ee_w = vee[:3], vee[3:6]
+        translation_w = R_w_ee @ t_ee
+        R_w_t = R_w_ee @ R_ee_t
+        p_t = p_ee + R_w_ee @ t_ee
+        v_task = R_w_t @ (v_ee_w + w_ee_w.T @ translation_w)
+        R_task_y, R_task_z = R_w_t[:, 1], R_w_t[:, 2]
+        x, y, z = p_t
+        nx, ny, nz = 2 * a * x + c * y + d, 2 * b * y + c * x + ee, -1.0
+        nn = np.sqrt(nx ** 2 + ny ** 2 + nz ** 2)
+        n = np.array([nx, ny, nz]) / nn
+        z_surf = a * x ** 2 + b * y ** 2 + c * x * y + d * x + ee * y + f
+        e["e1"][i] = z_surf - z
+        e["e2"][i] = 1.0 - float(n @ R_task_z)
+        e["e3"][i] = float(R_task_y[0])
+        e["e4"][i] = px_ref - x
+        e["e5"][i] = vy_ref - v_task[1]
+        e["p_task_z"][i] = z
+    e["p_ee_y"] = p_ee_all[1, :]
+    return e

@@ -1,0 +1,215 @@
+"""Parity tests proper: the HIP engine, called through the C ABI (libmpcbatch.so), against the
+CPU oracle on the same seeded inputs, against the committed golden vectors, and -- at
+BASELINE.json's full size -- through size-independent properties.
+
+Tolerance (fp64): q, qdot, u, poses within 1e-9 absolute of the oracle over the whole closed
+loop (north_star's contractual bound vs acados is 1e-6); integer outputs (status, iteration
+counts) identical.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as hp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from robotic_mpc_amd import engine
+
+    e = engine.MpcBatchEngine(0)
+    yield e
+    e.close()
+
+
+def _cfg(**kw):
+    from robotic_mpc_amd import config
+
+    return config.resolve_config(config.base_params(**kw))
+
+
+def _jitter(n, seed=0, **kw):
+    from robotic_mpc_amd import config
+
+    rng = np.random.default_rng(seed)
+    return [_cfg(q_0=config.BASE_PARAMS["q_0"] + rng.uniform(-0.1, 0.1, 6), **kw) for _ in range(n)]
+
+
+def _check(out, i, ref, atol=ATOL):
+    for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
+        np.testing.assert_allclose(out[k][i], ref[k], atol=atol, rtol=0, err_msg=k)
+    np.testing.assert_allclose(out["cost"][i], ref["cost"], atol=1e-9, rtol=1e-9)
+    np.testing.assert_allclose(out["residuals"][i], ref["residuals"], atol=1e-7)
+    for k in ("status", "sqp_iter", "qp_iter"):
+        np.testing.assert_array_equal(out[k][i], ref[k], err_msg=k)
+
+
+def test_native_library_is_the_path(eng):
+    """The engine object holds the in-tree HIP library and a real device handle."""
+    from robotic_mpc_amd import engine
+
+    assert os.path.samefile(eng.lib._name, engine.LIB_PATH)
+    assert eng.lib.mpcb_device_count() >= 1
+    info = eng.kernel_info()
+    assert info["vgprs"] > 0 and info["lds_bytes"] > 0
+
+
+@pytest.mark.parametrize("N,T,solver,B", [(20, 1.0, "SQP_RTI", 4), (10, 0.5, "SQP", 3), (100, 0.3, "SQP_RTI", 2),
+                                           (1, 0.1, "SQP_RTI", 1), (2, 0.1, "SQP", 1), (130, 0.05, "SQP_RTI", 2)])
+def test_engine_matches_oracle(eng, orc, ur10, ur10_rb, N, T, solver, B):
+    cfgs = _jitter(B, seed=N, prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
+    out = eng.run(cfgs, ur10)
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+
+
+def test_active_bounds_and_heterogeneous_parameters(eng, orc, ur10, ur10_rb):
+    cfgs = [
+        _cfg(prediction_horizon=15, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
+             qdot_0=np.array([0.5, 0.7, 0.5, 0, 0, 0.0])),
+        _cfg(prediction_horizon=15, simulation_time=0.3, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
+             w_qddot=0.05, px_ref=0.5, vy_ref=-0.02, surface_coeffs=dict(a=-0.1, b=0.12, c=0.0, d=0.02, e=-0.01, f=0.05)),
+        _cfg(prediction_horizon=15, simulation_time=0.3, q_min=np.full(6, -1e30), q_max=np.full(6, 1e30)),  # absent bounds
+    ]
+    out = eng.run(cfgs, ur10)
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+    assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6
+
+
+def test_ur5_chain(eng, orc):
+    from robotic_mpc_amd import robots
+
+    ch = robots.builtin_chain("ur5")
+    cfg = _cfg(robot_name="ur5", prediction_horizon=12, simulation_time=0.2, q_0=np.array([0.3, -1.2, 1.4, -1.0, -1.2, 0.2]),
+               qdot_0=np.zeros(6), px_ref=0.45)
+    out = eng.run([cfg], ch)
+    _check(out, 0, orc.run(orc.make_robot(ch), orc.make_params(cfg)))
+
+
+@pytest.mark.parametrize("name", sorted(mg.CASES))
+def test_engine_matches_golden_vectors(eng, ur10, name):
+    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    out = eng.run([mg.case_config(name)], ur10)
+    for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
+        np.testing.assert_allclose(out[k][0], g[k], atol=ATOL, rtol=0, err_msg=k)
+    for k in ("status", "sqp_iter", "qp_iter"):
+        np.testing.assert_array_equal(out[k][0], g[k])
+
+
+def test_chunked_launches_and_host_buffer_api_are_bitwise_identical(eng, ur10):
+    cfgs = _jitter(3, seed=5, prediction_horizon=25, simulation_time=0.4)
+    a = eng.run(cfgs, ur10)
+    b = eng.run(cfgs, ur10, step_chunk=7)       # state carried across launches in the HBM workspace
+    c = eng.run_host_buffers(cfgs, ur10)        # mpcb_run: library-owned device buffers, numpy in/out
+    for k in ("z", "u", "ee_pose", "cost", "residuals", "status", "qp_iter"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
+
+
+def test_call_order_and_argument_errors(eng, ur10):
+    from robotic_mpc_amd import engine
+
+    e2 = engine.MpcBatchEngine(0)
+    r = engine.MpcbResult()
+    assert e2.lib.mpcb_rollout(e2._h, 0, 1, C.byref(r), None) == -5          # MPCB_ESTATE: before setup
+    cfgs = _jitter(1, prediction_horizon=5, simulation_time=0.05)
+    pb = e2.setup(cfgs, ur10)
+    bufs = e2.alloc_results(pb)
+    with pytest.raises(engine.EngineError, match="continue"):
+        e2.rollout(bufs, 2, 3)                                               # does not continue at step 0
+    with pytest.raises(engine.EngineError, match="bounds"):
+        e2.rollout(bufs, 0, pb.Nsim + 1)
+    bad = engine.MpcbProblem(1, 0, 5, 1, 100, 50, 0, 0)
+    z = np.zeros(64)
+    assert e2.lib.mpcb_setup(e2._h, C.byref(bad), z.ctypes.data_as(engine._dp), z.ctypes.data_as(engine._dp)) == -1
+    e2.close()
+
+
+# ----------------------------------------------------------------------------- full size
+@pytest.fixture(scope="module")
+def full_run(eng, ur10):
+    """BASELINE.json configs[1]: batch 256, N=100, 600 steps, SQP_RTI, flat surface."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+
+    cfgs = bench.workload_configs(256, 100, 6.0, seed=0, solver="SQP_RTI")
+    cfgs[17] = cfgs[3]      # duplicates at different batch positions
+    cfgs[255] = cfgs[3]
+    return cfgs, eng.run(cfgs, ur10)
+
+
+def test_full_size_properties(full_run, ur10):
+    cfgs, out = full_run
+    assert (out["status"] == 0).all() and (out["sqp_iter"] == 1).all()
+    # position independence: identical simulations give bitwise identical logs
+    for k in ("z", "u", "ee_pose", "cost", "qp_iter"):
+        assert np.array_equal(out[k][3], out[k][17]) and np.array_equal(out[k][3], out[k][255]), k
+    # input bounds respected at every logged step
+    umax = cfgs[0]["umax"][None, :, None]
+    assert (np.abs(out["u"][:, :, 1:]) <= umax + 1e-7).all()
+    # the log obeys the plant recurrence z[:,i+1] = RK4(z[:,i], u[:,i+1]) (simulation_model.py:85-88,111-117)
+    z, u = out["z"], out["u"]
+    w, dt = 200.0, 0.01
+    q, v, uu = z[:, :6, :-1], z[:, 6:, :-1], u[:, :, 1:]
+    f = lambda vv: -w * vv + w * uu
+    k1 = f(v); v2 = v + 0.5 * dt * k1; k2 = f(v2); v3 = v + 0.5 * dt * k2; k3 = f(v3); v4 = v + dt * k3; k4 = f(v4)
+    vn = v + dt / 6 * k1 + dt / 3 * k2 + dt / 3 * k3 + dt / 6 * k4
+    qn = q + dt / 6 * v + dt / 3 * v2 + dt / 3 * v3 + dt / 6 * v4
+    np.testing.assert_allclose(z[:, 6:, 1:], vn, atol=1e-12)
+    np.testing.assert_allclose(z[:, :6, 1:], qn, atol=1e-12)
+    # logged poses are FK of the logged joint angles (independent numpy chain, subsample)
+    for i in (0, 100, 255):
+        for t in (0, 1, 300, 600):
+            T, _, _ = hp.fk_homogeneous(ur10, z[i, :6, t])
+            np.testing.assert_allclose(out["ee_pose"][i, :3, t], T[:3, 3], atol=1e-12)
+            np.testing.assert_allclose(out["ee_pose"][i, 3:, t].reshape(3, 3), T[:3, :3], atol=1e-12)
+    # closed loop converges onto the flat surface z = 0 and the px reference for every instance
+    pt = out["ee_pose"][:, :3, :] + 0.1 * out["ee_pose"][:, [5, 8, 11], :]
+    assert np.abs(pt[:, 2, -1]).max() < 5e-3 and np.abs(pt[:, 0, -1] - 0.4).max() < 5e-3
+    assert out["cost"][:, -1].max() < 1e-2 < out["cost"][:, 0].min()
+
+
+def test_full_size_spot_check_against_oracle(full_run, orc, ur10_rb):
+    cfgs, out = full_run
+    for i in (3, 128):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(cfgs[i])))
+
+
+def test_full_size_run_is_deterministic(full_run, eng, ur10):
+    cfgs, out = full_run
+    again = eng.run(cfgs, ur10)
+    for k in ("z", "u", "cost", "qp_iter"):
+        assert np.array_equal(out[k], again[k]), k
+
+
+def test_simulation_manager_end_to_end_on_gpu(orc):
+    from robotic_mpc_amd import SimulationManager, base_params
+
+    base = base_params(prediction_horizon=8, simulation_time=0.1)
+    grid = {"prediction_horizon": [6, 8], "w_qddot": [0.02, 0.05]}
+    sets = [dict(a=-0.1, b=0.1, c=-0.01, d=0.01, e=0.01, f=0.0), dict(a=-0.2, b=0.2, c=-0.01, d=0.01, e=0.01, f=0.0)]
+    g = SimulationManager(base)
+    g.grid_search(grid, surface_coeff_sets=sets)
+    res = g.run_all()
+    o = SimulationManager(base, runner=hp.oracle_runner)
+    o.grid_search(grid, surface_coeff_sets=sets)
+    ref = o.run_all()
+    assert [r["name"] for r in res] == [r["name"] for r in ref] and len(res) == 8
+    for a, b in zip(res, ref):
+        for k in ("q", "qdot", "u"):
+            np.testing.assert_allclose(a["data"][k], b["data"][k], atol=ATOL, rtol=0)
+        for k in ("e1", "e2", "e3", "e4", "e5"):
+            np.testing.assert_allclose(a["analysis"][k], b["analysis"][k], atol=1e-8)
+        assert abs(a["summary"]["weighted_rmse"] - b["summary"]["weighted_rmse"]) < 1e-8
+        assert a["summary"]["num_failures"] == 0
