@@ -1,0 +1,85 @@
+// Diagnostic microbenchmark (not product): times the three Riccati sweeps of mpc_core.h in
+// isolation, one wave per block, to separate "cost of the sweep code" from whole-kernel effects.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../robotic-mpc_amd/csrc/mpc_core.h"
+#include "../../robotic-mpc_amd/csrc/mpc_pack.h"
+using namespace mpcb;
+struct DevExec {
+    int lane;
+    template <class T> struct PerLane { T v; __device__ __forceinline__ T &at(int) { return v; } };
+    template <class F> __device__ __forceinline__ void par(F &&f) { f(lane); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    __device__ __forceinline__ double reduce_sum(const double *r) { double v = r[lane]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+    __device__ __forceinline__ double reduce_max(const double *r) { double v = r[lane]; for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return v; }
+    __device__ __forceinline__ double reduce_min(const double *r) { double v = r[lane]; for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return v; }
+    __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
+};
+template <int WHICH>
+__global__ __launch_bounds__(64) void k_sweep(Problem pb, const InstParams *params, const Robot *rb, double *ws, size_t stride, int reps)
+{
+    __shared__ Smem sm;
+    DevExec ex{(int)threadIdx.x};
+    load_constants(ex, sm, params + blockIdx.x, rb);
+    Ctx c{&pb, ws_carve(ws + blockIdx.x * stride, pb.N), &sm, pb.N};
+    Engine<DevExec> eng(ex, c);
+    for (int r = 0; r < reps; r++) {
+        if (WHICH == 0) eng.template riccati_backward<true>();
+        if (WHICH == 1) eng.template riccati_backward<false>();
+        if (WHICH == 2) eng.riccati_forward();
+        if (WHICH == 3) { double n[4]; eng.ipm_residuals(n); }
+        if (WHICH == 4) eng.ipm_step_lam_t();
+        if (WHICH == 5) eng.linearize(c.w.X, c.w.U, true);
+    }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+int main(int argc, char **argv)
+{
+    int B = argc > 1 ? atoi(argv[1]) : 256, N = argc > 2 ? atoi(argv[2]) : 100, reps = 20;
+    Problem pb{B, N, 10, 1, 100, 50, 0, 0};
+    double p[64] = {0};
+    p[0] = 0.01; p[1] = 1e-6; p[2] = 1e-8; p[3] = 0.01; p[4] = 0.02; p[5] = 0.4; p[6] = 0.05;
+    for (int j = 0; j < 6; j++) { p[8 + j] = 200; p[14 + j] = 0.3 * j - 0.7; p[20 + j] = 0.1; p[26 + j] = -6.28; p[32 + j] = 6.28; p[38 + j] = -2; p[44 + j] = 2; }
+    for (int j = 0; j < 5; j++) p[56 + j] = 50;
+    std::vector<InstParams> hp(B);
+    for (int i = 0; i < B; i++) pack_inst_params(p, &hp[i]);
+    Robot rb{};
+    for (int i = 0; i < 7; i++) { rb.place[i][0] = rb.place[i][4] = rb.place[i][8] = 1; rb.place[i][11] = 0.2; }
+    for (int i = 0; i < 6; i++) rb.axis[i][i % 2 ? 1 : 2] = 1;
+    rb.t_ee[2] = 0.1;
+    InstParams *dp; Robot *drb; double *ws;
+    size_t stride = ws_doubles_per_instance(N);
+    CK(hipMalloc(&dp, B * sizeof(InstParams))); CK(hipMalloc(&drb, sizeof(Robot))); CK(hipMalloc(&ws, B * stride * 8));
+    CK(hipMemcpy(dp, hp.data(), B * sizeof(InstParams), hipMemcpyHostToDevice)); CK(hipMemcpy(drb, &rb, sizeof(Robot), hipMemcpyHostToDevice));
+    // benign data: identity-ish P so the recursion stays finite
+    std::vector<double> h(B * stride, 0.0);
+    for (size_t i = 0; i < h.size(); i++) h[i] = 1e-3 * ((i * 2654435761u) % 1000) / 1000.0;
+    for (int b = 0; b < B; b++) {
+        Ws w = ws_carve(h.data() + b * stride, N);
+        for (int k = 0; k <= N; k++) {
+            for (int j = 0; j < 24; j++) { w.QLAM[k * 24 + j] = 0.5; w.QT[k * 24 + j] = 0.7; }
+            for (int j = 0; j < 12; j++) w.RIC[k * W_RIC + RIC_GAM + j] = 0.7;
+        }
+    }
+    CK(hipMemcpy(ws, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const char *names[] = {"fact", "bwd", "fwd", "residuals", "step_lam_t", "linearize"};
+    for (int which = 0; which < 6; which++) {
+        for (int it = 0; it < 2; it++) {
+            CK(hipEventRecord(e0));
+            switch (which) {
+                case 0: hipLaunchKernelGGL(k_sweep<0>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+                case 1: hipLaunchKernelGGL(k_sweep<1>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+                case 2: hipLaunchKernelGGL(k_sweep<2>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+                case 3: hipLaunchKernelGGL(k_sweep<3>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+                case 4: hipLaunchKernelGGL(k_sweep<4>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+                case 5: hipLaunchKernelGGL(k_sweep<5>, dim3(B), dim3(64), 0, 0, pb, dp, drb, ws, stride, reps); break;
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (it == 1) printf("%-10s B=%d N=%d: %.1f us per call, %.3f us per stage\n", names[which], B, N, ms * 1e3 / reps, ms * 1e3 / reps / N);
+        }
+    }
+    return 0;
+}
