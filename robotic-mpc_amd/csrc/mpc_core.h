@@ -2,12 +2,12 @@
 //
 // One wavefront = one closed-loop simulation (Simulator.run, simulator.py:199-241).
 // The code is written as bulk-synchronous phases `ex.par([&](int lane){...})`: inside a
-// phase a lane only reads data produced by earlier phases (LDS or the HBM workspace) and
-// writes entries no other lane reads in that phase; `par` ends with a wavefront-scope fence.
-// On the GPU `Ex` is DevExec (mpc_kernel.hip: lane = threadIdx.x, fence = compiler-only
-// because a single wave executes its LDS/VMEM instructions in order).  tests/emu
-// instantiates the same template with a host executor that loops over the 64 lanes -- a
-// debugging aid for a container without a GPU, never part of the product library.
+// phase a lane only reads data produced by earlier phases and writes entries no other lane
+// reads in that phase; `par` ends with a wavefront-scope fence.  On the GPU `Ex` is DevExec
+// (mpc_kernel.hip: lane = threadIdx.x; the fence is compiler-only because a single wave
+// executes its LDS/VMEM instructions in order).  tests/emu instantiates the same template
+// with a host executor that loops over the 64 lanes -- a debugging aid for a container
+// without a GPU, never part of the product library.
 //
 // Algorithm (what acados + HPIPM do behind trajectory_optimizer.py:183-186):
 //   SQP_RTI / SQP with Gauss-Newton Hessian  ->  OCP-QP in delta form  ->  Mehrotra
@@ -18,12 +18,14 @@
 // coupling is the rank-5 task term 50*dt*G'G.  The 6x6 R~ is factorised redundantly by all
 // lanes (LDL'), the 18 right-hand sides (12 columns of S~, 6 of I) are solved one per lane.
 //
-// Memory: the sequential sweeps never wait on HBM inside the recursion.  Each stage's inputs
-// live in ONE contiguous record (RIC / FAC / PM, mpc_layout.h); a sweep loads the record of
-// stage k-1 into registers while stage k+1 computes (coalesced 8 B/lane loads) and drops it
-// into an LDS staging buffer one stage before it is consumed.
+// Memory: every pass streams CHUNKS of consecutive stage records HBM -> LDS -> HBM
+// (mpc_layout.h).  One IPM iteration is five passes: factorisation sweep, forward sweep +
+// step lengths, corrector + backward solve, forward sweep + step lengths, update + residuals.
 #pragma once
 #include "mpc_kin.h"
+
+// 16-way manual unrolling with individually named registers (see Engine::load_rect)
+#define MPC_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 namespace mpcb {
 
@@ -36,33 +38,37 @@ constexpr double BOUND_INF = 1e29;
 #define PROF_T0(v)
 #define PROF_ADD(i, v)
 #endif
-enum { PF_LIN = 0, PF_NRES, PF_INIT, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_STEP, PF_MUAFF, PF_CORR, PF_UPD, PF_NUPD,
-       PF_PLANT, PF_TOTAL, PF_COUNT_IPM };
+enum { PF_NLP = 0, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_MERIT, PF_PLANT, PF_TOTAL, PF_COUNT_IPM, PF_IO };
 
+// The LDS working set is reached through the executor (ex.smem(), ex.pool()) and never through a
+// stored pointer: inside a non-inlined pass a pointer loaded from `this` is a generic (flat)
+// pointer, and every LDS access through it becomes a flat_load/flat_store with vmcnt+lgkmcnt
+// waits.  The accessors return the __shared__ objects themselves, so the compiler keeps ds_* ops.
 struct Ctx {
     const Problem *pb;
     Ws w;
-    Smem *sm;
+    int pool_n;     // doubles in the LDS chunk pool
     int N;
 };
 
-struct PfRegs {
-    double d[5];
-};
+// HBM pointers inside the bulk copies carry the global address space explicitly (same reason).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPC_GLOBAL __attribute__((address_space(1)))
+#else
+#define MPC_GLOBAL
+#endif
+
+// 16-byte register type of the bulk copies: a native vector (a struct here turns every load into
+// a memcpy to a stack slot that SROA does not always remove)
+typedef double D2 __attribute__((ext_vector_type(2)));
 
 // ---- bound bookkeeping (trajectory_optimizer.py:164-171: lbu on stages 0..N-1, lbx on
 // q of stages 1..N-1; x_0 is fixed by lbx_0 = ubx_0, simulator.py:210-211) -------------
 MPC_HD bool has_comp(int N, int k, int j) { return j < 6 ? (k < N) : (k >= 1 && k < N); }
 MPC_HD double bnd_lo(const InstParams &P, int j) { return j < 6 ? P.umin[j] : P.qmin[j - 6]; }
 MPC_HD double bnd_hi(const InstParams &P, int j) { return j < 6 ? P.umax[j] : P.qmax[j - 6]; }
-MPC_HD double cur_val(const Ws &w, int k, int j) { return j < 6 ? w.U[k * W_U + j] : w.X[k * W_X + (j - 6)]; }
-
-// element e of the concatenation of three HBM segments (0 beyond the end)
-MPC_HD double seg_load(int e, const double *p0, int n0, const double *p1, int n1, const double *p2, int n2)
-{
-    const double *p = e < n0 ? p0 + e : (e < n0 + n1 ? p1 + (e - n0) : p2 + (e - n0 - n1));
-    return e < n0 + n1 + n2 ? *p : 0.0;
-}
+MPC_HD int imin(int a, int b) { return a < b ? a : b; }
+MPC_HD int imax(int a, int b) { return a > b ? a : b; }
 
 // lower-triangle index e -> (i, j), i >= j
 MPC_HD void tri_index(int e, int &i, int &j)
@@ -74,8 +80,9 @@ MPC_HD void tri_index(int e, int &i, int &j)
 
 // Copy the instance parameters and the kinematic constants into LDS (once per launch).
 template <class Ex>
-MPC_HD void load_constants(Ex &ex, Smem &sm, const InstParams *P, const Robot *rb)
+MPC_HD void load_constants(Ex &ex, const InstParams *P, const Robot *rb)
 {
+    Smem &sm = ex.smem();
     ex.par([&](int lane) {
         const double *ps = reinterpret_cast<const double *>(P);
         double *pd = reinterpret_cast<double *>(&sm.P);
@@ -91,8 +98,7 @@ struct Engine {
     Ex &ex;
     Ctx c;
     int N;
-    double lin_cost;  // cost of the linearisation currently held in LIN/RIC
-    typename Ex::template PerLane<PfRegs> pf;
+    double lin_cost;  // cost of the linearisation currently held in G2
 #ifdef MPCB_PROFILE
     double prof[NPROF];
 #endif
@@ -104,99 +110,243 @@ struct Engine {
 #endif
     }
 
-    // =========================================================================== NLP level
-    // Linearise at the iterate (X,U): task residual + Jacobian per stage, dynamics defect,
-    // cost = sum_k dt/2 r'Wr (acados get_cost(), simulator.py:221).  Lane <-> stage.
-    MPC_HD double linearize(const double *X, const double *U, bool jac)
+    // =========================================================================== chunk I/O
+    // Rectangle = columns [C0, C0+W) of stages [k_lo, k_hi] of a group with row stride LDG.
+    // The LDS copy is compact (row stride W).  W, C0, LDG even: 16-byte accesses, every lane
+    // issues its loads back to back (two register sets in flight) before touching LDS.
+    template <int W, int C0, int LDG>
+    MPC_HD void load_rect(double *l, const double *g, int k_lo, int k_hi)
+    {
+        constexpr int W2h = W / 2;
+        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
+        const int tot = (k_hi - k_lo + 1) * W2h;
+        const MPC_GLOBAL D2 *gb = (const MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
+        D2 *lb = reinterpret_cast<D2 *>(l);
+        PROF_T0(t0);
+        ex.par([&](int lane) {
+            // Sixteen individually named 16-byte registers per lane: all loads of a batch are issued
+            // back to back and retired with counted vmcnt waits.  (A local array here lands in scratch
+            // memory in the full kernel and serialises every load on `s_waitcnt vmcnt(0)`.)
+            for (int base = 0; base < tot; base += WAVE * 16) {
+#define MPC_LD(u)                                                  \
+    const int e##u = imin(base + u * WAVE + lane, tot - 1);         \
+    const int s##u = e##u / W2h;                                   \
+    const D2 r##u = gb[(size_t)s##u * (LDG / 2) + (e##u - s##u * W2h)];
+#define MPC_ST(u) lb[e##u] = r##u;
+                MPC_REP16(MPC_LD)
+                MPC_REP16(MPC_ST)
+#undef MPC_LD
+#undef MPC_ST
+            }
+        });
+        PROF_ADD(PF_IO, t0);
+    }
+
+    template <int W, int C0, int LDG>
+    MPC_HD void store_rect(const double *l, double *g, int k_lo, int k_hi)
+    {
+        constexpr int W2h = W / 2;
+        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
+        const int tot = (k_hi - k_lo + 1) * W2h;
+        MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
+        const D2 *lb = reinterpret_cast<const D2 *>(l);
+        PROF_T0(t0);
+        ex.par([&](int lane) {
+            for (int base = 0; base < tot; base += WAVE * 16) {
+#define MPC_LD(u)                                          \
+    const int e##u = imin(base + u * WAVE + lane, tot - 1); \
+    const D2 r##u = lb[e##u];
+#define MPC_ST(u)                      \
+    {                                  \
+        const int s_ = e##u / W2h;     \
+        gb[(size_t)s_ * (LDG / 2) + (e##u - s_ * W2h)] = r##u; \
+    }
+                MPC_REP16(MPC_LD)
+                MPC_REP16(MPC_ST)
+#undef MPC_LD
+#undef MPC_ST
+            }
+        });
+        PROF_ADD(PF_IO, t0);
+    }
+
+    MPC_HD int chunk_len(int per_stage, int halo_doubles) const
+    {
+        const int ch = (c.pool_n - halo_doubles) / per_stage;
+        return imax(1, imin(ch, N + 1));
+    }
+
+    // =========================================================================== NLP pass
+    // One pass over the horizon that (optionally) applies the SQP/RTI step to the iterate
+    // (acados ocp_nlp_update_variables_sqp), linearises at the new iterate -- task residual and
+    // Jacobian per stage (lane <-> stage), dynamics defect, cost = sum_k dt/2 r'Wr (acados
+    // get_cost(), simulator.py:221) -- and evaluates acados' ocp_nlp_res_compute inf-norms
+    // [stat, eq, ineq, comp] with the NLP multipliers (RTI: the QP's; SQP: the blended ones).
+    MPC_PASS double nlp_pass(double alpha, bool do_update, bool sqp_mult, double *res4)
     {
         PROF_T0(t0);
-        Smem &sm = *c.sm;
+        Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
-        Ws &w = c.w;
         const int Nl = N;
-        ex.par([&](int lane) {
-            double csum = 0.0;
-            for (int k = lane; k <= Nl; k += WAVE) {
-                double *lin = w.LIN + (size_t)k * W_LIN;
-                double *ric = w.RIC + (size_t)k * W_RIC;
-                if (k < Nl) {
-                    const double *x = X + (size_t)k * W_X, *u = U + (size_t)k * W_U, *xn = X + (size_t)(k + 1) * W_X;
-                    double xx[12], uu[6];
-#pragma unroll
-                    for (int i = 0; i < 12; i++) xx[i] = x[i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) uu[i] = u[i];
-                    if (jac) task_lin<true>(rb, P, xx, xx + 6, lin, ric);
-                    else task_lin<false>(rb, P, xx, xx + 6, lin, ric);
-                    double s = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NTASK; i++) s += P.w_task[i] * lin[LIN_R + i] * lin[LIN_R + i];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const double uj = uu[j], vj = xx[6 + j];
-                        const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
-                        s += 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
-                        if (jac) {
-                            w.BD[(size_t)k * W_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - xn[j];
-                            w.BD[(size_t)k * W_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - xn[6 + j];
+        const int W5M = 60;  // NPI, NLAM, NT
+        const int CH = chunk_len(W1 + W5M + W2, 2 * (W1 + W5M));
+        double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
+        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+            const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
+            double *v1 = ex.pool();                       // rows lo..hi, W1
+            double *v5 = v1 + (size_t)(CH + 2) * W1;   // rows lo..hi, 60
+            double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, W2
+            load_rect<W1, 0, W1>(v1, c.w.G1, lo, hi);
+            if (sqp_mult) load_rect<60, 0, W5>(v5, c.w.G5, lo, hi);
+            if (do_update) {
+                ex.par([&](int lane) {
+                    const int rows = hi - lo + 1;
+                    // chunks run in increasing k: the lower halo row was already updated (and stored) by
+                    // the previous chunk, the upper one has not been touched yet
+                    for (int e = lane; e < rows * NW; e += WAVE) {
+                        const int s = e / NW, ci = e - s * NW;
+                        if (lo + s < k0) continue;
+                        double *r1 = v1 + (size_t)s * W1;
+                        if (ci < 12) r1[O_X + ci] += alpha * r1[O_QW + 6 + ci];
+                        else if (lo + s < Nl) r1[O_U + ci - 12] += alpha * r1[O_QW + ci - 12];
+                    }
+                    if (sqp_mult) {
+                        for (int e = lane; e < rows * 60; e += WAVE) {
+                            const int s = e / 60, ci = e - s * 60;
+                            if (lo + s < k0) continue;
+                            const double *r1 = v1 + (size_t)s * W1;
+                            double *r5 = v5 + (size_t)s * 60;
+                            // NPI | NLAM | NT  <-  blend towards QPI | QLAM | QT (contiguous in G1 from O_QPI)
+                            r5[ci] += alpha * (r1[O_QPI + ci] - r5[ci]);
                         }
                     }
-                    csum += 0.5 * P.dt * s;
-                } else if (jac) {
-#pragma unroll
-                    for (int i = 0; i < W_LIN; i++) lin[i] = 0.0;
-#pragma unroll
-                    for (int i = 0; i < RIC_GAM; i++) ric[i] = 0.0;
-                }
+                });
             }
-            sm.red[0][lane] = csum;
-        });
-        const double r = ex.reduce_sum(sm.red[0]);
-        PROF_ADD(PF_LIN, t0);
-        return r;
-    }
-
-    // y_ki = w_i (r_ki + G_ki . delta_k): weighted (linearised) task residual.  Flat (k,i).
-    MPC_HD void phase_y(const double *QW)
-    {
-        const InstParams &P = c.sm->P;
-        Ws &w = c.w;
-        const int total = N * NTASK;
-        ex.par([&](int lane) {
-            for (int e = lane; e < total; e += WAVE) {
-                const int k = e / NTASK, i = e - k * NTASK;
-                double *lin = w.LIN + (size_t)k * W_LIN;
-                const double *ric = w.RIC + (size_t)k * W_RIC;
-                double v = lin[LIN_R + i];
-                if (QW) {
-                    const double *dw = QW + (size_t)k * W_QW;
+            ex.par([&](int lane) {
+                double csum = 0.0;
+                for (int k = k0 + lane; k <= k1; k += WAVE) {
+                    double *rec = v2 + (size_t)(k - k0) * W2;
+                    if (k < Nl) {
+                        const double *r1 = v1 + (size_t)(k - lo) * W1, *rn = r1 + W1;
+                        double xx[12], uu[6];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v += ric[RIC_GQ + i * 6 + j] * dw[6 + j];
-                    if (i == 4) {
+                        for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
 #pragma unroll
-                        for (int j = 0; j < 6; j++) v += ric[RIC_GV + j] * dw[12 + j];
+                        for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i];
+                        task_lin<true>(rb, P, xx, xx + 6, rec);
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) {
+                            const double r = rec[O_R + i];
+                            s += P.w_task[i] * r * r;
+                            rec[O_Y + i] = P.w_task[i] * r;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const double uj = uu[j], vj = xx[6 + j];
+                            const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
+                            s += 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
+                            rec[O_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - rn[O_X + j];
+                            rec[O_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - rn[O_X + 6 + j];
+                        }
+                        csum += 0.5 * P.dt * s;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
                     }
                 }
-                lin[LIN_Y + i] = P.w_task[i] * v;
+                sm.red[0][lane] = csum;
+            });
+            cost += ex.reduce_sum(sm.red[0]);
+            if (res4) {
+                ex.par([&](int lane) {
+                    double a_s = 0, a_e = 0, a_i = 0, a_c = 0;
+                    const int rows = k1 - k0 + 1;
+                    for (int e = lane; e < rows * NW; e += WAVE) {
+                        const int s = e / NW, ci = e - s * NW, k = k0 + s;
+                        const double *pi_k = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NPI : v1 + (size_t)(k - lo) * W1 + O_QPI;
+                        const double *pi_m = sqp_mult ? v5 + (size_t)(imax(k - 1, lo) - lo) * 60 + O_NPI
+                                                      : v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
+                        const double *lam = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NLAM : v1 + (size_t)(k - lo) * W1 + O_QLAM;
+                        const double *tt = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NT : v1 + (size_t)(k - lo) * W1 + O_QT;
+                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * W1, v2 + (size_t)s * W2, false, pi_k, pi_m);
+                        if (ci < NB && has_comp(Nl, k, ci)) {
+                            const double cur = v1[(size_t)(k - lo) * W1 + (ci < 6 ? O_U + ci : O_X + ci - 6)];
+                            if (bnd_lo(P, ci) > -BOUND_INF) {
+                                v -= lam[ci];
+                                a_i = fmax(a_i, fabs((bnd_lo(P, ci) - cur) + tt[ci]));
+                                a_c = fmax(a_c, fabs(lam[ci] * tt[ci]));
+                            }
+                            if (bnd_hi(P, ci) < BOUND_INF) {
+                                v += lam[12 + ci];
+                                a_i = fmax(a_i, fabs((cur - bnd_hi(P, ci)) + tt[12 + ci]));
+                                a_c = fmax(a_c, fabs(lam[12 + ci] * tt[12 + ci]));
+                            }
+                        }
+                        if (ci >= 6 && k == 0) v = 0.0;
+                        a_s = fmax(a_s, fabs(v));
+                        if (ci < NX && k < Nl) a_e = fmax(a_e, fabs(v2[(size_t)s * W2 + O_BD + ci]));
+                    }
+                    if (k0 == 0 && lane < NX) a_i = fmax(a_i, fabs(sm.xhat[lane] - v1[O_X + lane]));  // lbx_0 = ubx_0 = x_hat
+                    sm.red[0][lane] = a_s; sm.red[1][lane] = a_e; sm.red[2][lane] = a_i; sm.red[3][lane] = a_c;
+                });
+                rs = fmax(rs, ex.reduce_max(sm.red[0]));
+                re = fmax(re, ex.reduce_max(sm.red[1]));
+                ri = fmax(ri, ex.reduce_max(sm.red[2]));
+                rc = fmax(rc, ex.reduce_max(sm.red[3]));
             }
-        });
+            if (do_update) {
+                store_rect<18, 0, W1>(v1 + (size_t)(k0 - lo) * W1, c.w.G1, k0, k1, W1);
+                if (sqp_mult) store_rect<60, 0, W5>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, 60);
+            }
+            store_rect<W2_LIN, 0, W2>(v2, c.w.G2, k0, k1, W2);
+        }
+        if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
+        PROF_ADD(PF_NLP, t0);
+        return cost;
     }
 
-    // Stationarity element (k,c) of the Lagrangian: cost gradient (+ GN Hessian * delta),
-    // dynamics adjoints; bound multipliers are added by the caller.
-    MPC_HD double stat_elem(int k, int cidx, const double *QW, const double *PI) const
+    // store_rect variant whose LDS source has a row stride different from the rectangle width
+    template <int W, int C0, int LDG>
+    MPC_HD void store_rect(const double *l, double *g, int k_lo, int k_hi, int ldl)
     {
-        const InstParams &P = c.sm->P;
-        const Ws &w = c.w;
+        constexpr int W2h = W / 2;
+        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
+        const int tot = (k_hi - k_lo + 1) * W2h;
+        MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
+        const D2 *lb = reinterpret_cast<const D2 *>(l);
+        const int ldl2 = ldl / 2;
+        PROF_T0(t0);
+        ex.par([&](int lane) {
+            for (int base = 0; base < tot; base += WAVE * 16) {
+#define MPC_LD(u)                                          \
+    const int e##u = imin(base + u * WAVE + lane, tot - 1); \
+    const int s##u = e##u / W2h, c##u = e##u - s##u * W2h;  \
+    const D2 r##u = lb[(size_t)s##u * ldl2 + c##u];
+#define MPC_ST(u) gb[(size_t)s##u * (LDG / 2) + c##u] = r##u;
+                MPC_REP16(MPC_LD)
+                MPC_REP16(MPC_ST)
+#undef MPC_LD
+#undef MPC_ST
+            }
+        });
+        PROF_ADD(PF_IO, t0);
+    }
+
+    // Stationarity element (k,c) of the Lagrangian: cost gradient (+ GN Hessian * delta when
+    // `with_delta`, through y), dynamics adjoints; bound multipliers are added by the caller.
+    // r1 = G1 record of stage k, r2 = G2 record of stage k (y must be current).
+    MPC_HD double stat_elem(int k, int cidx, const double *r1, const double *r2, bool with_delta, const double *pk,
+                            const double *pm) const
+    {
+        const InstParams &P = ex.smem().P;
         double val = 0.0;
-        const double *pk = PI + (size_t)k * W_PI;
-        const double *pm = PI + (size_t)(k > 0 ? k - 1 : 0) * W_PI;
         if (cidx < 6) {
             if (k >= N) return 0.0;
             const int j = cidx;
-            double uj = w.U[k * W_U + j], vj = w.X[k * W_X + 6 + j];
-            if (QW) { uj += QW[k * W_QW + j]; vj += QW[k * W_QW + 12 + j]; }
+            double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+            if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
             const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
             val = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
             val += P.b1[j] * pk[j] + P.b2[j] * pk[6 + j];
@@ -204,11 +354,9 @@ struct Engine {
             if (k == 0) return 0.0;
             const int j = cidx - 6;
             if (k < N) {
-                const double *lin = w.LIN + (size_t)k * W_LIN;
-                const double *ric = w.RIC + (size_t)k * W_RIC;
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < NTASK; i++) s += ric[RIC_GQ + i * 6 + j] * lin[LIN_Y + i];
+                for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
                 val = P.dt * s + pk[j];
             }
             val -= pm[j];
@@ -216,12 +364,10 @@ struct Engine {
             if (k == 0) return 0.0;
             const int j = cidx - 12;
             if (k < N) {
-                const double *lin = w.LIN + (size_t)k * W_LIN;
-                const double *ric = w.RIC + (size_t)k * W_RIC;
-                double uj = w.U[k * W_U + j], vj = w.X[k * W_X + 6 + j];
-                if (QW) { uj += QW[k * W_QW + j]; vj += QW[k * W_QW + 12 + j]; }
+                double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+                if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
                 const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
-                val = P.dt * (ric[RIC_GV + j] * lin[LIN_Y + 4] + c2 * (vj - uj));
+                val = P.dt * (r2[O_GV + j] * r2[O_Y + 4] + c2 * (vj - uj));
                 val += P.a12[j] * pk[j] + P.a22[j] * pk[6 + j];
             }
             val -= pm[6 + j];
@@ -229,342 +375,198 @@ struct Engine {
         return val;
     }
 
-    // acados ocp_nlp_res_compute: inf-norms [stat, eq, ineq, comp] at the NLP iterate with
-    // multipliers (PI, LAM, T).  Needs a fresh linearisation (LIN, RIC, BD).
-    MPC_HD void nlp_residuals(const double *PI, const double *LAM, const double *T, double *res4)
+    // =========================================================================== IPM: residual pass
+    // MODE 0 (init, HPIPM warm_start = 2): keep (w, pi, lam, t) of the previous QP, clamp
+    // lam, t >= 0.1, embed x0.  MODE 1: apply the Newton step with length `a` (HPIPM
+    // update_var).  Then QP residuals, Gamma and the condensed gradient gt of the Newton system
+    // (HPIPM compute_Gamma_gamma).  out: nrm = [g, b, d, m], smu = sum(lam*t), nc = #bound sides.
+    MPC_PASS void residual_pass(int mode, double a, double *nrm, double *smu_out, double *nc_out)
     {
         PROF_T0(t0);
-        Smem &sm = *c.sm;
+        Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        Ws &w = c.w;
-        phase_y(nullptr);
-        const int tot_g = (N + 1) * NW, tot_b = N * NX, tot_c = (N + 1) * NB;
-        ex.par([&](int lane) {
-            double rs = 0, re = 0, ri = 0, rc = 0;
-            for (int e = lane; e < tot_g; e += WAVE) {
-                const int k = e / NW, ci = e - k * NW;
-                double v = stat_elem(k, ci, nullptr, PI);
-                if (ci < NB && has_comp(N, k, ci)) {
-                    if (bnd_lo(P, ci) > -BOUND_INF) v -= LAM[k * W_LAM + ci];
-                    if (bnd_hi(P, ci) < BOUND_INF) v += LAM[k * W_LAM + 12 + ci];
-                }
-                if (ci >= 6 && k == 0) v = 0.0;
-                rs = fmax(rs, fabs(v));
-            }
-            for (int e = lane; e < tot_b; e += WAVE) re = fmax(re, fabs(w.BD[e]));
-            for (int e = lane; e < tot_c; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                if (!has_comp(N, k, j)) continue;
-                const double v = cur_val(w, k, j);
-                if (bnd_lo(P, j) > -BOUND_INF) {
-                    const double l = LAM[k * W_LAM + j], t = T[k * W_T + j];
-                    ri = fmax(ri, fabs((bnd_lo(P, j) - v) + t));
-                    rc = fmax(rc, fabs(l * t));
-                }
-                if (bnd_hi(P, j) < BOUND_INF) {
-                    const double l = LAM[k * W_LAM + 12 + j], t = T[k * W_T + 12 + j];
-                    ri = fmax(ri, fabs((v - bnd_hi(P, j)) + t));
-                    rc = fmax(rc, fabs(l * t));
-                }
-            }
-            if (lane < NX) ri = fmax(ri, fabs(sm.xhat[lane] - w.X[lane]));  // lbx_0 = ubx_0 = x_hat
-            sm.red[0][lane] = rs; sm.red[1][lane] = re; sm.red[2][lane] = ri; sm.red[3][lane] = rc;
-        });
-        res4[0] = ex.reduce_max(sm.red[0]);
-        res4[1] = ex.reduce_max(sm.red[1]);
-        res4[2] = ex.reduce_max(sm.red[2]);
-        res4[3] = ex.reduce_max(sm.red[3]);
-        PROF_ADD(PF_NRES, t0);
-    }
-
-    // =========================================================================== IPM pieces
-    // HPIPM init with warm_start = 2: keep (w, pi, lam, t) of the previous QP, clamp
-    // lam, t >= 0.1; embed x0.  Returns the number of active (finite) bound sides.
-    MPC_HD double ipm_init()
-    {
-        PROF_T0(t0);
-        Smem &sm = *c.sm;
-        const InstParams &P = sm.P;
-        Ws &w = c.w;
-        const int tot = (N + 1) * NB;
-        ex.par([&](int lane) {
-            double nc = 0.0;
-            for (int e = lane; e < tot; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                const bool hc = has_comp(N, k, j);
-                const bool lo = hc && bnd_lo(P, j) > -BOUND_INF, hi = hc && bnd_hi(P, j) < BOUND_INF;
-                double *lam = w.QLAM + (size_t)k * W_LAM, *t = w.QT + (size_t)k * W_T;
-                if (lo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); nc += 1.0; }
-                else { lam[j] = 0.0; t[j] = 1.0; }
-                if (hi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); nc += 1.0; }
-                else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
-            }
-            if (lane < NX) w.QW[6 + lane] = sm.xhat[lane] - w.X[lane];
-            if (lane < NU) w.QW[(size_t)N * W_QW + lane] = 0.0;
-            sm.red[0][lane] = nc;
-        });
-        const double r = ex.reduce_sum(sm.red[0]);
-        PROF_ADD(PF_INIT, t0);
-        return r;
-    }
-
-    // QP residuals at (QW, QPI, QLAM, QT); also Gamma and the condensed gradient gt of the
-    // Newton system (HPIPM compute_Gamma_gamma).  nrm = [g, b, d, m], returns sum(lam*t).
-    MPC_HD double ipm_residuals(double *nrm)
-    {
-        PROF_T0(t0);
-        Smem &sm = *c.sm;
-        const InstParams &P = sm.P;
-        Ws &w = c.w;
-        phase_y(w.QW);
-        const int tot_g = (N + 1) * NW, tot_b = N * NX;
-        ex.par([&](int lane) {
-            double ng = 0, nb = 0, nd = 0, nm = 0, smu = 0;
-            for (int e = lane; e < tot_g; e += WAVE) {
-                const int k = e / NW, ci = e - k * NW;
-                double *ric = w.RIC + (size_t)k * W_RIC;
-                double rg = stat_elem(k, ci, w.QW, w.QPI);
-                double gt = rg;
-                if (ci < NB) {
-                    const bool hc = has_comp(N, k, ci);
-                    const bool lo = hc && bnd_lo(P, ci) > -BOUND_INF, hi = hc && bnd_hi(P, ci) < BOUND_INF;
-                    const double v = hc ? cur_val(w, k, ci) : 0.0, dv = w.QW[(size_t)k * W_QW + ci];
-                    double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
-                    if (lo) {
-                        const double l = w.QLAM[k * W_LAM + ci], t = w.QT[k * W_T + ci];
-                        rdl = dv - (bnd_lo(P, ci) - v) - t;
-                        rml = l * t;
-                        rg -= l;
-                        gam += l / t;
-                        smu += rml;
-                        nd = fmax(nd, fabs(rdl)); nm = fmax(nm, fabs(rml));
-                    }
-                    if (hi) {
-                        const double l = w.QLAM[k * W_LAM + 12 + ci], t = w.QT[k * W_T + 12 + ci];
-                        rdu = (bnd_hi(P, ci) - v) - dv - t;
-                        rmu = l * t;
-                        rg += l;
-                        gam += l / t;
-                        smu += rmu;
-                        nd = fmax(nd, fabs(rdu)); nm = fmax(nm, fabs(rmu));
-                    }
-                    gt = rg;
-                    if (lo) gt += (rml + w.QLAM[k * W_LAM + ci] * rdl) / w.QT[k * W_T + ci];
-                    if (hi) gt -= (rmu + w.QLAM[k * W_LAM + 12 + ci] * rdu) / w.QT[k * W_T + 12 + ci];
-                    w.RD[k * W_RD + ci] = rdl; w.RD[k * W_RD + 12 + ci] = rdu;
-                    w.RM[k * W_RM + ci] = rml; w.RM[k * W_RM + 12 + ci] = rmu;
-                    ric[RIC_GAM + ci] = gam;
-                }
-                w.RG[e] = rg;
-                ric[RIC_GT + ci] = gt;
-                ng = fmax(ng, fabs(rg));
-            }
-            for (int e = lane; e < tot_b; e += WAVE) {
-                const int k = e / NX, i = e - k * NX;
-                const double *dw = w.QW + (size_t)k * W_QW, *dn = w.QW + (size_t)(k + 1) * W_QW;
-                double v;
-                if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
-                else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
-                v += w.BD[e] - dn[6 + i];
-                w.RIC[(size_t)k * W_RIC + RIC_RB + i] = v;
-                nb = fmax(nb, fabs(v));
-            }
-            sm.red[0][lane] = ng; sm.red[1][lane] = nb; sm.red[2][lane] = nd; sm.red[3][lane] = nm;
-            sm.red[4][lane] = smu;
-        });
-        nrm[0] = ex.reduce_max(sm.red[0]);
-        nrm[1] = ex.reduce_max(sm.red[1]);
-        nrm[2] = ex.reduce_max(sm.red[2]);
-        nrm[3] = ex.reduce_max(sm.red[3]);
-        const double r = ex.reduce_sum(sm.red[4]);
-        PROF_ADD(PF_RES, t0);
-        return r;
-    }
-
-    // Centering-corrector right-hand side (HPIPM compute_centering_correction):
-    // rm <- lam*t + dlam_aff*dt_aff - sigma*mu ; rebuild gt.
-    MPC_HD void ipm_corrector_rhs(double sigma_mu)
-    {
-        PROF_T0(t0);
-        const InstParams &P = c.sm->P;
-        Ws &w = c.w;
-        const int tot = (N + 1) * NB;
-        ex.par([&](int lane) {
-            for (int e = lane; e < tot; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                if (!has_comp(N, k, j)) continue;
-                double gt = w.RG[k * W_RG + j];
-                if (bnd_lo(P, j) > -BOUND_INF) {
-                    const double l = w.QLAM[k * W_LAM + j], t = w.QT[k * W_T + j];
-                    const double rm = l * t + w.DLAM[k * W_DLAM + j] * w.DT[k * W_DT + j] - sigma_mu;
-                    w.RM[k * W_RM + j] = rm;
-                    gt += (rm + l * w.RD[k * W_RD + j]) / t;
-                }
-                if (bnd_hi(P, j) < BOUND_INF) {
-                    const double l = w.QLAM[k * W_LAM + 12 + j], t = w.QT[k * W_T + 12 + j];
-                    const double rm = l * t + w.DLAM[k * W_DLAM + 12 + j] * w.DT[k * W_DT + 12 + j] - sigma_mu;
-                    w.RM[k * W_RM + 12 + j] = rm;
-                    gt -= (rm + l * w.RD[k * W_RD + 12 + j]) / t;
-                }
-                w.RIC[(size_t)k * W_RIC + RIC_GT + j] = gt;
-            }
-        });
-        PROF_ADD(PF_CORR, t0);
-    }
-
-    // dt, dlam from the primal step (HPIPM compute_lam_t) and the largest feasible step.
-    MPC_HD double ipm_step_lam_t()
-    {
-        PROF_T0(t0);
-        Smem &sm = *c.sm;
-        const InstParams &P = sm.P;
-        Ws &w = c.w;
-        const int tot = (N + 1) * NB;
-        ex.par([&](int lane) {
-            double alpha = 1.0;
-            for (int e = lane; e < tot; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                const bool hc = has_comp(N, k, j);
-                const double dv = w.DW[(size_t)k * W_DW + j];
-                double dtl = 0, dll = 0, dtu = 0, dlu = 0;
-                if (hc && bnd_lo(P, j) > -BOUND_INF) {
-                    const double l = w.QLAM[k * W_LAM + j], t = w.QT[k * W_T + j];
-                    dtl = dv + w.RD[k * W_RD + j];
-                    dll = -(w.RM[k * W_RM + j] + l * dtl) / t;
-                    if (dll < 0 && l + alpha * dll < 0) alpha = -l / dll;
-                    if (dtl < 0 && t + alpha * dtl < 0) alpha = -t / dtl;
-                }
-                if (hc && bnd_hi(P, j) < BOUND_INF) {
-                    const double l = w.QLAM[k * W_LAM + 12 + j], t = w.QT[k * W_T + 12 + j];
-                    dtu = -dv + w.RD[k * W_RD + 12 + j];
-                    dlu = -(w.RM[k * W_RM + 12 + j] + l * dtu) / t;
-                    if (dlu < 0 && l + alpha * dlu < 0) alpha = -l / dlu;
-                    if (dtu < 0 && t + alpha * dtu < 0) alpha = -t / dtu;
-                }
-                w.DT[k * W_DT + j] = dtl; w.DLAM[k * W_DLAM + j] = dll;
-                w.DT[k * W_DT + 12 + j] = dtu; w.DLAM[k * W_DLAM + 12 + j] = dlu;
-            }
-            sm.red[0][lane] = alpha;
-        });
-        const double r = ex.reduce_min(sm.red[0]);
-        PROF_ADD(PF_STEP, t0);
-        return r;
-    }
-
-    MPC_HD double ipm_mu_aff(double alpha)
-    {
-        PROF_T0(t0);
-        Ws &w = c.w;
-        Smem &sm = *c.sm;
-        const int tot = (N + 1) * NL;
-        ex.par([&](int lane) {
-            double s = 0.0;
-            for (int e = lane; e < tot; e += WAVE) {
-                // masked-out sides carry lam = 0, dlam = 0 -> contribute 0
-                s += (w.QLAM[e] + alpha * w.DLAM[e]) * (w.QT[e] + alpha * w.DT[e]);
-            }
-            sm.red[0][lane] = s;
-        });
-        const double r = ex.reduce_sum(sm.red[0]);
-        PROF_ADD(PF_MUAFF, t0);
-        return r;
-    }
-
-    MPC_HD void ipm_update(double a)
-    {
-        PROF_T0(t0);
-        const InstParams &P = c.sm->P;
-        Ws &w = c.w;
-        const int tw = (N + 1) * NW, tp = N * NX, tc = (N + 1) * NB;
-        ex.par([&](int lane) {
-            for (int e = lane; e < tw; e += WAVE) w.QW[e] += a * w.DW[e];
-            for (int e = lane; e < tp; e += WAVE) w.QPI[e] += a * w.DPI[e];
-            for (int e = lane; e < tc; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                if (!has_comp(N, k, j)) continue;
-                if (bnd_lo(P, j) > -BOUND_INF) {
-                    w.QLAM[k * W_LAM + j] = fmax(w.QLAM[k * W_LAM + j] + a * w.DLAM[k * W_DLAM + j], 1e-16);
-                    w.QT[k * W_T + j] = fmax(w.QT[k * W_T + j] + a * w.DT[k * W_DT + j], 1e-16);
-                }
-                if (bnd_hi(P, j) < BOUND_INF) {
-                    w.QLAM[k * W_LAM + 12 + j] = fmax(w.QLAM[k * W_LAM + 12 + j] + a * w.DLAM[k * W_DLAM + 12 + j], 1e-16);
-                    w.QT[k * W_T + 12 + j] = fmax(w.QT[k * W_T + 12 + j] + a * w.DT[k * W_DT + 12 + j], 1e-16);
-                }
-            }
-        });
-        PROF_ADD(PF_UPD, t0);
-    }
-
-    // =========================================================================== Riccati
-    static constexpr int STG_HALF = STG_DOUBLES / 2;
-    // staging offsets of the solve sweeps
-    static constexpr int SB_PM = 0, SB_K = 144, SB_GT = 216, SB_RB = 234, SB_TOT = 246;      // backward solve
-    static constexpr int SF_FAC = 0, SF_PM = 126, SF_RB = 270, SF_TOT = 282;                  // forward
-
-    // Backward sweep.  FACT: rebuild (R~, S~, P) per stage from Gamma and the Jacobians and
-    // write Kfb = R~^-1 S~, R~^-1, P_k; always propagates the vector part (gt, rb) -> p_k, h_u.
-    template <bool FACT>
-    MPC_HD void riccati_backward()
-    {
-        PROF_T0(t0);
-        Smem &sm = *c.sm;
-        const InstParams &P = sm.P;
-        Ws &w = c.w;
         const int Nl = N;
-        // fetch of the stage-k record into registers (coalesced), commit into LDS staging
-        auto issue = [&](int lane, int k) {
-            PfRegs &r = pf.at(lane);
-            if (FACT) {
-                const double *ric = w.RIC + (size_t)k * W_RIC;
-                r.d[0] = ric[lane];
-                r.d[1] = lane < W_RIC - WAVE ? ric[WAVE + lane] : 0.0;
-            } else {
-                const double *p0 = w.PM + (size_t)(k + 1) * W_PM, *p1 = w.FAC + (size_t)k * W_FAC + FAC_K,
-                             *p2 = w.RIC + (size_t)k * W_RIC + RIC_GT;
-#pragma unroll
-                for (int i = 0; i < 4; i++) r.d[i] = seg_load(lane + WAVE * i, p0, 144, p1, 72, p2, 30);
-            }
-        };
-        auto commit = [&](int lane, int buf) {
-            const PfRegs &r = pf.at(lane);
-            double *s = sm.stg + buf * STG_HALF;
-            if (FACT) {
-                s[lane] = r.d[0];
-                if (lane < W_RIC - WAVE) s[WAVE + lane] = r.d[1];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (lane + WAVE * i < SB_TOT) s[lane + WAVE * i] = r.d[i];
-            }
-        };
-        // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x ; first stage record
-        ex.par([&](int lane) {
-            if (FACT) {
-                for (int e = lane; e < 144; e += WAVE) { sm.M[0][e] = 0.0; w.PM[(size_t)Nl * W_PM + e] = 0.0; }
-            }
-            if (lane < NX) {
-                const double v = w.RIC[(size_t)Nl * W_RIC + RIC_GT + 6 + lane];
-                sm.pv[0][lane] = v;
-                w.FAC[(size_t)Nl * W_FAC + FAC_PV + lane] = v;
-            }
-            issue(lane, Nl - 1);
-        });
-        ex.par([&](int lane) {
-            commit(lane, 0);
-            if (Nl >= 2) issue(lane, Nl - 2);
-        });
-        int cur = 0, sb = 0;
-        for (int k = Nl - 1; k >= 0; k--) {
-            const double *stg = sm.stg + sb * STG_HALF;
-            double *fac = w.FAC + (size_t)k * W_FAC;
-            const int nxt = cur ^ 1;
-            const double *gam = stg + RIC_GAM;
-            const double *gt = FACT ? stg + RIC_GT : stg + SB_GT;
-            const double *rb = FACT ? stg + RIC_RB : stg + SB_RB;
-            // ---- F0: R~ (21 lower entries), S~ (72), m~ = p_{k+1} + P_{k+1} rb_k (12)
+        constexpr int W3D = 78, W3R = 66, WG = 42;
+        const int per = W1 + W3D + W2_LIN + W3R + WG;
+        const int CH = chunk_len(per, 2 * (W1 + W3D));
+        double ng = 0, nb = 0, nd = 0, nm = 0, smu = 0, nc = 0;
+        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+            const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
+            double *v1 = ex.pool();                        // rows lo..hi, W1
+            double *v3d = v1 + (size_t)(CH + 2) * W1;   // rows lo..hi, DW|DPI|DLAM|DT
+            double *v2 = v3d + (size_t)(CH + 2) * W3D;  // rows k0..k1, compact [R..GV] (60)
+            double *v3r = v2 + (size_t)CH * W2_LIN;     // rows k0..k1, RG|RD|RM
+            double *vg = v3r + (size_t)CH * W3R;        // rows k0..k1, Gamma(12) | gt(18) | rb(12)
+            load_rect<W1, 0, W1>(v1, c.w.G1, lo, hi);
+            if (mode == 1) load_rect<W3D, O_DW, W3>(v3d, c.w.G3, lo, hi);
+            load_rect<W2_LIN, 0, W2>(v2, c.w.G2, k0, k1);
             ex.par([&](int lane) {
-                const double *M = FACT ? sm.M[cur] : stg + SB_PM;
-                if (FACT) {
+                const int rows = hi - lo + 1;
+                double ncl = 0.0;
+                if (mode == 1) {
+                    // (lower halo row: already updated and stored by the previous chunk)
+                    for (int e = lane; e < rows * NW; e += WAVE) {
+                        const int s = e / NW, ci = e - s * NW;
+                        if (lo + s >= k0) v1[(size_t)s * W1 + O_QW + ci] += a * v3d[(size_t)s * W3D + ci];
+                    }
+                    for (int e = lane; e < (rows - 1) * NX; e += WAVE) {  // pi_k += a * dpi stored at stage k+1
+                        const int s = e / NX, i = e - s * NX;
+                        if (lo + s >= k0 && lo + s < Nl) v1[(size_t)s * W1 + O_QPI + i] += a * v3d[(size_t)(s + 1) * W3D + 18 + i];
+                    }
+                }
+                for (int e = lane; e < rows * NB; e += WAVE) {
+                    const int s = e / NB, j = e - s * NB, k = lo + s;
+                    if (k < k0 || k > k1) continue;  // multipliers are only needed on own rows
+                    const bool hc = has_comp(Nl, k, j);
+                    const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                    double *lam = v1 + (size_t)s * W1 + O_QLAM, *t = v1 + (size_t)s * W1 + O_QT;
+                    const double *dl = v3d + (size_t)s * W3D + 30, *dt = v3d + (size_t)s * W3D + 54;
+                    if (mode == 0) {
+                        if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
+                        else { lam[j] = 0.0; t[j] = 1.0; }
+                        if (bhi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); }
+                        else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                        ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
+                    } else {
+                        if (blo) { lam[j] = fmax(lam[j] + a * dl[j], 1e-16); t[j] = fmax(t[j] + a * dt[j], 1e-16); }
+                        if (bhi) { lam[12 + j] = fmax(lam[12 + j] + a * dl[12 + j], 1e-16); t[12 + j] = fmax(t[12 + j] + a * dt[12 + j], 1e-16); }
+                    }
+                }
+                if (mode == 0) {
+                    if (lo == 0 && lane < NX) v1[O_QW + 6 + lane] = sm.xhat[lane] - v1[O_X + lane];
+                    if (hi == Nl && lane < NU) v1[(size_t)(Nl - lo) * W1 + O_QW + lane] = 0.0;
+                }
+                sm.red[5][lane] = ncl;
+            });
+            if (mode == 0) nc += ex.reduce_sum(sm.red[5]);
+            // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
+            ex.par([&](int lane) {
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * NTASK; e += WAVE) {
+                    const int s = e / NTASK, i = e - s * NTASK, k = k0 + s;
+                    double *r2 = v2 + (size_t)s * W2_LIN;
+                    if (k >= Nl) continue;
+                    const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW;
+                    double v = r2[O_R + i];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v += r2[O_GQ + i * 6 + j] * dw[6 + j];
+                    if (i == 4) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
+                    }
+                    r2[O_Y + i] = P.w_task[i] * v;
+                }
+            });
+            // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg
+            ex.par([&](int lane) {
+                double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * NW; e += WAVE) {
+                    const int s = e / NW, ci = e - s * NW, k = k0 + s;
+                    const double *r1 = v1 + (size_t)(k - lo) * W1;
+                    const double *r2 = v2 + (size_t)s * W2_LIN;
+                    const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
+                    double *o3 = v3r + (size_t)s * W3R, *og = vg + (size_t)s * 42;
+                    double rg = stat_elem(k, ci, r1, r2, true, pk, pm);
+                    double gt = rg;
+                    if (ci < NB) {
+                        const bool hc = has_comp(Nl, k, ci);
+                        const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                        const double v = hc ? r1[ci < 6 ? O_U + ci : O_X + ci - 6] : 0.0, dv = r1[O_QW + ci];
+                        double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                        if (blo) {
+                            const double l = r1[O_QLAM + ci], t = r1[O_QT + ci];
+                            rdl = dv - (bnd_lo(P, ci) - v) - t;
+                            rml = l * t;
+                            rg -= l;
+                            gam += l / t;
+                            a_mu += rml;
+                            a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                        }
+                        if (bhi) {
+                            const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci];
+                            rdu = (bnd_hi(P, ci) - v) - dv - t;
+                            rmu = l * t;
+                            rg += l;
+                            gam += l / t;
+                            a_mu += rmu;
+                            a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
+                        }
+                        gt = rg;
+                        if (blo) gt += (rml + r1[O_QLAM + ci] * rdl) / r1[O_QT + ci];
+                        if (bhi) gt -= (rmu + r1[O_QLAM + 12 + ci] * rdu) / r1[O_QT + 12 + ci];
+                        o3[O_RD + ci] = rdl; o3[O_RD + 12 + ci] = rdu;
+                        o3[O_RM + ci] = rml; o3[O_RM + 12 + ci] = rmu;
+                        og[ci] = gam;
+                    }
+                    o3[O_RG + ci] = rg;
+                    og[12 + ci] = gt;
+                    a_g = fmax(a_g, fabs(rg));
+                }
+                for (int e = lane; e < rows * NX; e += WAVE) {
+                    const int s = e / NX, i = e - s * NX, k = k0 + s;
+                    double v = 0.0;
+                    if (k < Nl) {
+                        const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW, *dn = dw + W1;
+                        if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
+                        else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
+                        v += v2[(size_t)s * W2_LIN + O_BD + i] - dn[6 + i];
+                        a_b = fmax(a_b, fabs(v));
+                    }
+                    vg[(size_t)s * WG + 30 + i] = v;
+                }
+                sm.red[0][lane] = a_g; sm.red[1][lane] = a_b; sm.red[2][lane] = a_d; sm.red[3][lane] = a_m;
+                sm.red[4][lane] = a_mu;
+            });
+            ng = fmax(ng, ex.reduce_max(sm.red[0]));
+            nb = fmax(nb, ex.reduce_max(sm.red[1]));
+            nd = fmax(nd, ex.reduce_max(sm.red[2]));
+            nm = fmax(nm, ex.reduce_max(sm.red[3]));
+            smu += ex.reduce_sum(sm.red[4]);
+            store_rect<78, O_QW, W1>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, W1);
+            store_rect<10, 0, W2>(v2, c.w.G2, k0, k1, W2_LIN);        // r (unchanged) and y
+            store_rect<WG, O_GAM, W2>(vg, c.w.G2, k0, k1, WG);        // Gamma | gt | rb
+            store_rect<W3R, 0, W3>(v3r, c.w.G3, k0, k1, W3R);         // RG | RD | RM
+        }
+        nrm[0] = ng; nrm[1] = nb; nrm[2] = nd; nrm[3] = nm;
+        *smu_out = smu;
+        if (nc_out) *nc_out = nc;
+        PROF_ADD(PF_RES, t0);
+    }
+
+    // =========================================================================== Riccati passes
+    // Factorisation sweep (backward over chunks): per stage rebuild (R~, S~, P) from Gamma and the
+    // Jacobians, Kfb = R~^-1 S~, R~^-1, P_k, and propagate the vector part (gt, rb) -> p_k, h_u.
+    MPC_PASS void fact_pass()
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = N;
+        constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12)
+        const int CH = chunk_len(WR + W4, 0);
+        int cur = 0;
+        for (int k1 = Nl; k1 >= 0; k1 -= CH) {
+            const int k0 = imax(k1 - CH + 1, 0);
+            double *vr = ex.pool();                   // rows k0..k1, 78: GQ 0, GV 30, GAM 36, GT 48, RB 66
+            double *vf = vr + (size_t)CH * WR;     // rows k0..k1, W4
+            load_rect<WR, O_GQ, W2>(vr, c.w.G2, k0, k1);
+            for (int k = k1; k >= k0; k--) {
+                const double *ric = vr + (size_t)(k - k0) * WR;
+                double *fac = vf + (size_t)(k - k0) * W4;
+                const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
+                const int nxt = cur ^ 1;
+                if (k == Nl) {
+                    // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x
+                    ex.par([&](int lane) {
+                        for (int e = lane; e < 144; e += WAVE) { sm.M[cur][e] = 0.0; fac[O_PM + e] = 0.0; }
+                        if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
+                    });
+                    continue;
+                }
+                // ---- F0: R~ (21 lower entries), S~ (72), m~ = p_{k+1} + P_{k+1} rb_k (12)
+                ex.par([&](int lane) {
+                    const double *M = sm.M[cur];
                     if (lane < 21) {
                         int i, j;
                         tri_index(lane, i, j);
@@ -591,21 +593,18 @@ struct Engine {
                         }
                         sm.St[e] = s;
                     }
-                }
-                if (lane < NX) {
-                    double s = sm.pv[cur][lane];
+                    if (lane < NX) {
+                        double s = sm.pv[cur][lane];
 #pragma unroll
-                    for (int j = 0; j < NX; j++) s += M[lane * 12 + j] * rb[j];
-                    sm.mt[lane] = s;
-                }
-            });
-            // ---- F1: LDL' of R~ (redundant), one right-hand side per lane; vector part;
-            //          stage k-1's record moves from registers to the other staging buffer
-            ex.par([&](int lane) {
-                double hu[6];
+                        for (int j = 0; j < NX; j++) s += M[lane * 12 + j] * rbv[j];
+                        sm.mt[lane] = s;
+                    }
+                });
+                // ---- F1: LDL' of R~ (redundant), one right-hand side per lane; vector part
+                ex.par([&](int lane) {
+                    double hu[6];
 #pragma unroll
-                for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
-                if (FACT) {
+                    for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
                     double L[6][6], dd[6], dinv[6];
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
@@ -641,153 +640,276 @@ struct Engine {
                         }
                         if (lane < 12) {
 #pragma unroll
-                            for (int i = 0; i < 6; i++) { fac[FAC_K + i * 12 + lane] = x[i]; sm.Kf[i * 12 + lane] = x[i]; }
+                            for (int i = 0; i < 6; i++) { fac[O_K + i * 12 + lane] = x[i]; sm.Kf[i * 12 + lane] = x[i]; }
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 6; i++) fac[FAC_RI + i * 6 + (lane - 12)] = x[i];
+                            for (int i = 0; i < 6; i++) fac[O_RI + i * 6 + (lane - 12)] = x[i];
                         }
                     }
-                }
-                if (lane < NX) {
-                    double hx = gt[6 + lane];
-                    if (lane < 6) hx += sm.mt[lane];
-                    else hx += P.a12[lane - 6] * sm.mt[lane - 6] + P.a22[lane - 6] * sm.mt[lane];
-                    double pj = hx;
-                    const double *Kc = FACT ? sm.Kf : stg + SB_K;
+                    if (lane < NX) {
+                        double hx = gt[6 + lane];
+                        if (lane < 6) hx += sm.mt[lane];
+                        else hx += P.a12[lane - 6] * sm.mt[lane - 6] + P.a22[lane - 6] * sm.mt[lane];
+                        sm.hx[lane] = hx;  // p_j = hx_j - sum_m Kfb(m,j) hu_m is finished in F2
+                    }
+                    if (lane < 6) {
+                        double v = hu[0];
 #pragma unroll
-                    for (int m = 0; m < 6; m++) pj -= Kc[m * 12 + lane] * hu[m];
-                    sm.pv[nxt][lane] = pj;
-                    fac[FAC_PV + lane] = pj;
-                }
-                if (lane < 6) {
-                    double v = hu[0];
-#pragma unroll
-                    for (int j = 1; j < 6; j++) v = lane == j ? hu[j] : v;
-                    fac[FAC_HU + lane] = v;
-                }
-                if (k >= 1) {
-                    commit(lane, sb ^ 1);
-                    if (k >= 2) issue(lane, k - 2);
-                }
-            });
-            // ---- F2: P_k = H_xx + Gamma_q + A'MA - S~' Kfb   (78 unique entries)
-            if (FACT && k > 0) {
-                ex.par([&](int lane) {
-                    const double *M = sm.M[cur];
-                    const double *gq = stg + RIC_GQ, *gv = stg + RIC_GV;
-                    for (int e = lane; e < 78; e += WAVE) {
-                        int i, j;
-                        tri_index(e, i, j);
-                        double v;
-                        if (i < 6) {  // qq
-                            v = M[i * 12 + j];
-                            double s = 0.0;
-#pragma unroll
-                            for (int r = 0; r < NTASK; r++) s += P.w_task[r] * gq[r * 6 + i] * gq[r * 6 + j];
-                            v += P.dt * s;
-                            if (i == j) v += gam[6 + i];
-                        } else if (j < 6) {  // vq: row 6+a, col b
-                            const int a = i - 6, b = j;
-                            v = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
-                            v += P.dt * P.w_task[4] * gv[a] * gq[4 * 6 + b];
-                        } else {  // vv
-                            const int a = i - 6, b = j - 6;
-                            const double cq = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
-                            const double cv = P.a12[a] * M[a * 12 + 6 + b] + P.a22[a] * M[(6 + a) * 12 + 6 + b];
-                            v = cq * P.a12[b] + cv * P.a22[b];
-                            v += P.dt * P.w_task[4] * gv[a] * gv[b];
-                            if (a == b) v += P.dt * P.w_qddot * P.cq[a] * P.cq[a];
-                        }
-#pragma unroll
-                        for (int m = 0; m < 6; m++) v -= sm.St[m * 12 + i] * sm.Kf[m * 12 + j];
-                        sm.M[nxt][i * 12 + j] = v;
-                        sm.M[nxt][j * 12 + i] = v;
-                        w.PM[(size_t)k * W_PM + i * 12 + j] = v;
-                        w.PM[(size_t)k * W_PM + j * 12 + i] = v;
+                        for (int j = 1; j < 6; j++) v = lane == j ? hu[j] : v;
+                        fac[O_HU + lane] = v;
                     }
                 });
+                // ---- F2: p_k, and P_k = H_xx + Gamma_q + A'MA - S~' Kfb   (78 unique entries)
+                ex.par([&](int lane) {
+                    const double *M = sm.M[cur];
+                    const double *gq = ric, *gv = ric + 30;
+                    if (lane < NX) {
+                        double pj = sm.hx[lane];
+#pragma unroll
+                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + lane] * fac[O_HU + m];
+                        sm.pv[nxt][lane] = pj;
+                        fac[O_PV + lane] = pj;
+                    }
+                    if (k > 0) {
+                        for (int e = lane; e < 78; e += WAVE) {
+                            int i, j;
+                            tri_index(e, i, j);
+                            double v;
+                            if (i < 6) {  // qq
+                                v = M[i * 12 + j];
+                                double s = 0.0;
+#pragma unroll
+                                for (int r = 0; r < NTASK; r++) s += P.w_task[r] * gq[r * 6 + i] * gq[r * 6 + j];
+                                v += P.dt * s;
+                                if (i == j) v += gam[6 + i];
+                            } else if (j < 6) {  // vq: row 6+a, col b
+                                const int a = i - 6, b = j;
+                                v = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
+                                v += P.dt * P.w_task[4] * gv[a] * gq[4 * 6 + b];
+                            } else {  // vv
+                                const int a = i - 6, b = j - 6;
+                                const double cq = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
+                                const double cv = P.a12[a] * M[a * 12 + 6 + b] + P.a22[a] * M[(6 + a) * 12 + 6 + b];
+                                v = cq * P.a12[b] + cv * P.a22[b];
+                                v += P.dt * P.w_task[4] * gv[a] * gv[b];
+                                if (a == b) v += P.dt * P.w_qddot * P.cq[a] * P.cq[a];
+                            }
+#pragma unroll
+                            for (int m = 0; m < 6; m++) v -= sm.St[m * 12 + i] * sm.Kf[m * 12 + j];
+                            sm.M[nxt][i * 12 + j] = v;
+                            sm.M[nxt][j * 12 + i] = v;
+                            fac[O_PM + i * 12 + j] = v;
+                            fac[O_PM + j * 12 + i] = v;
+                        }
+                    }
+                });
+                cur = nxt;
             }
-            cur = nxt;
-            sb ^= 1;
+            store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
         }
-        PROF_ADD(FACT ? PF_FACT : PF_BWD, t0);
+        PROF_ADD(PF_FACT, t0);
     }
 
-    // Forward sweep: du = -Kfb dx - Rinv h_u ; dx+ = A dx + B du + rb ; dpi = P dx+ + p.
-    MPC_HD void riccati_forward()
+    // Centering-corrector right-hand side (HPIPM compute_centering_correction: rm <- lam*t +
+    // dlam_aff*dt_aff - sigma*mu, rebuild gt) followed by the backward SOLVE sweep on the
+    // existing factorisation.
+    MPC_PASS void corrector_bwd_pass(double sigma_mu)
     {
         PROF_T0(t0);
-        Smem &sm = *c.sm;
+        Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        Ws &w = c.w;
         const int Nl = N;
-        auto issue = [&](int lane, int k) {
-            PfRegs &r = pf.at(lane);
-            const double *p0 = w.FAC + (size_t)k * W_FAC, *p1 = w.PM + (size_t)k * W_PM,
-                         *p2 = w.RIC + (size_t)k * W_RIC + RIC_RB;
-#pragma unroll
-            for (int i = 0; i < 5; i++) r.d[i] = seg_load(lane + WAVE * i, p0, 126, p1, 144, p2, 12);
-        };
-        auto commit = [&](int lane, int buf) {
-            const PfRegs &r = pf.at(lane);
-            double *s = sm.stg + buf * STG_HALF;
-#pragma unroll
-            for (int i = 0; i < 5; i++)
-                if (lane + WAVE * i < SF_TOT) s[lane + WAVE * i] = r.d[i];
-        };
-        ex.par([&](int lane) {
-            if (lane < NX) sm.dx[0][lane] = 0.0;  // dx_0 = 0: x_0 is pinned by ipm_init
-            issue(lane, 0);
-        });
-        ex.par([&](int lane) {
-            commit(lane, 0);
-            issue(lane, 1);  // N >= 1
-        });
-        int cur = 0, sb = 0;
-        for (int k = 0; k <= Nl; k++) {
-            const int nxt = cur ^ 1;
-            const double *stg = sm.stg + sb * STG_HALF;
-            // W0: lanes 0..5 -> du_k ; lanes 6..17 -> dpi_{k-1} = P_k dx_k + p_k ; lanes 18..29 log dx_k
+        constexpr int WLT = 48, WGR = 30;
+        const int CH = chunk_len(WLT + W3 + WGR + W4, W4);
+        int cur = 0;
+        for (int k1 = Nl; k1 >= 0; k1 -= CH) {
+            const int k0 = imax(k1 - CH + 1, 0), kh = imin(k1 + 1, Nl);
+            double *vlt = ex.pool();                        // rows k0..k1: QLAM | QT
+            double *v3 = vlt + (size_t)CH * WLT;         // rows k0..k1: G3 full
+            double *vgr = v3 + (size_t)CH * W3;          // rows k0..k1: GT(18) | RB(12)
+            double *v4 = vgr + (size_t)CH * WGR;         // rows k0..kh: G4 full
+            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
+            load_rect<W3, 0, W3>(v3, c.w.G3, k0, k1);
+            load_rect<WGR, O_GT, W2>(vgr, c.w.G2, k0, k1);
+            load_rect<W4, 0, W4>(v4, c.w.G4, k0, kh);
             ex.par([&](int lane) {
-                if (lane < 18) {
-                    const bool isu = lane < 6;
-                    if ((isu && k < Nl) || (!isu && k >= 1)) {
-                        const double *row = isu ? stg + SF_FAC + FAC_K + lane * 12 : stg + SF_PM + (lane - 6) * 12;
-                        double s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NX; j++) s += row[j] * sm.dx[cur][j];
-                        if (isu) {
-#pragma unroll
-                            for (int m = 0; m < 6; m++) s += stg[SF_FAC + FAC_RI + lane * 6 + m] * stg[SF_FAC + FAC_HU + m];
-                            s = -s;
-                            sm.du[lane] = s;
-                            w.DW[(size_t)k * W_DW + lane] = s;
-                        } else {
-                            w.DPI[(size_t)(k - 1) * W_DPI + (lane - 6)] = s + stg[SF_FAC + FAC_PV + (lane - 6)];
-                        }
-                    } else if (isu) {
-                        w.DW[(size_t)k * W_DW + lane] = 0.0;  // stage N has no input
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * NB; e += WAVE) {
+                    const int s = e / NB, j = e - s * NB, k = k0 + s;
+                    if (!has_comp(Nl, k, j)) continue;
+                    const double *lt = vlt + (size_t)s * WLT;
+                    double *r3 = v3 + (size_t)s * W3;
+                    double gt = r3[O_RG + j];
+                    if (bnd_lo(P, j) > -BOUND_INF) {
+                        const double l = lt[j], t = lt[24 + j];
+                        const double rm = l * t + r3[O_DLAM + j] * r3[O_DT + j] - sigma_mu;
+                        r3[O_RM + j] = rm;
+                        gt += (rm + l * r3[O_RD + j]) / t;
                     }
-                } else if (lane < 30) {
-                    w.DW[(size_t)k * W_DW + 6 + (lane - 18)] = sm.dx[cur][lane - 18];
+                    if (bnd_hi(P, j) < BOUND_INF) {
+                        const double l = lt[12 + j], t = lt[36 + j];
+                        const double rm = l * t + r3[O_DLAM + 12 + j] * r3[O_DT + 12 + j] - sigma_mu;
+                        r3[O_RM + 12 + j] = rm;
+                        gt -= (rm + l * r3[O_RD + 12 + j]) / t;
+                    }
+                    vgr[(size_t)s * WGR + j] = gt;
                 }
             });
-            if (k == Nl) break;
-            // W1: dx_{k+1}; next stage's record -> other staging buffer
-            ex.par([&](int lane) {
-                if (lane < NX) {
-                    double v;
-                    if (lane < 6) v = sm.dx[cur][lane] + P.a12[lane] * sm.dx[cur][6 + lane] + P.b1[lane] * sm.du[lane];
-                    else v = P.a22[lane - 6] * sm.dx[cur][lane] + P.b2[lane - 6] * sm.du[lane - 6];
-                    sm.dx[nxt][lane] = v + stg[SF_RB + lane];
+            for (int k = k1; k >= k0; k--) {
+                const double *gt = vgr + (size_t)(k - k0) * WGR, *rbv = gt + 18;
+                double *fac = v4 + (size_t)(k - k0) * W4;
+                const int nxt = cur ^ 1;
+                if (k == Nl) {
+                    ex.par([&](int lane) {
+                        if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
+                    });
+                    continue;
                 }
-                commit(lane, sb ^ 1);
-                if (k + 2 <= Nl) issue(lane, k + 2);
-            });
-            cur = nxt;
-            sb ^= 1;
+                const double *Mn = fac + W4 + O_PM;  // P_{k+1}
+                ex.par([&](int lane) {
+                    if (lane < NX) {
+                        double s = sm.pv[cur][lane];
+#pragma unroll
+                        for (int j = 0; j < NX; j++) s += Mn[lane * 12 + j] * rbv[j];
+                        sm.mt[lane] = s;
+                    }
+                });
+                ex.par([&](int lane) {
+                    double hu[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
+                    if (lane < NX) {
+                        double hx = gt[6 + lane];
+                        if (lane < 6) hx += sm.mt[lane];
+                        else hx += P.a12[lane - 6] * sm.mt[lane - 6] + P.a22[lane - 6] * sm.mt[lane];
+                        double pj = hx;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) pj -= fac[O_K + m * 12 + lane] * hu[m];
+                        sm.pv[nxt][lane] = pj;
+                        fac[O_PV + lane] = pj;
+                    }
+                    if (lane >= 32 && lane < 38) {  // a different lane set than the readers of fac[O_K..]
+                        const int jj = lane - 32;
+                        double v = hu[0];
+#pragma unroll
+                        for (int j = 1; j < 6; j++) v = jj == j ? hu[j] : v;
+                        fac[O_HU + jj] = v;
+                    }
+                });
+                cur = nxt;
+            }
+            store_rect<24, O_RM, W3>(v3 + O_RM, c.w.G3, k0, k1, W3);
+            store_rect<18, O_HU, W4>(v4 + O_HU, c.w.G4, k0, k1, W4);
         }
+        PROF_ADD(PF_BWD, t0);
+    }
+
+    // Forward sweep: du = -Kfb dx - Rinv h_u ; dx+ = A dx + B du + rb ; dpi = P dx+ + p, then
+    // dt, dlam from the primal step (HPIPM compute_lam_t), the largest feasible step and the
+    // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.
+    MPC_PASS double forward_step_pass(double *S)
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = N;
+        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78;
+        const int CH = chunk_len(W4 + WRB + WLT + WR + WO, 0);
+        double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
+        ex.par([&](int lane) {
+            if (lane < NX) sm.dx[0][lane] = 0.0;  // dx_0 = 0: x_0 is pinned by the init pass
+        });
+        int cur = 0;
+        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+            const int k1 = imin(k0 + CH - 1, Nl);
+            double *v4 = ex.pool();                      // rows k0..k1, G4
+            double *vrb = v4 + (size_t)CH * W4;       // RB
+            double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
+            double *vr = vlt + (size_t)CH * WLT;      // RD | RM
+            double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
+            load_rect<W4, 0, W4>(v4, c.w.G4, k0, k1);
+            load_rect<WRB, O_RB, W2>(vrb, c.w.G2, k0, k1);
+            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
+            load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
+            for (int k = k0; k <= k1; k++) {
+                const int nxt = cur ^ 1;
+                const double *fac = v4 + (size_t)(k - k0) * W4;
+                double *o = vo + (size_t)(k - k0) * WO;
+                // W0: lanes 0..5 -> du_k ; lanes 6..17 -> dpi_{k-1} = P_k dx_k + p_k ; lanes 18..29 log dx_k
+                ex.par([&](int lane) {
+                    if (lane < 18) {
+                        const bool isu = lane < 6;
+                        double s = 0.0;
+                        if ((isu && k < Nl) || (!isu && k >= 1)) {
+                            const double *row = isu ? fac + O_K + lane * 12 : fac + O_PM + (lane - 6) * 12;
+#pragma unroll
+                            for (int j = 0; j < NX; j++) s += row[j] * sm.dx[cur][j];
+                            if (isu) {
+#pragma unroll
+                                for (int m = 0; m < 6; m++) s += fac[O_RI + lane * 6 + m] * fac[O_HU + m];
+                                s = -s;
+                            } else {
+                                s += fac[O_PV + (lane - 6)];
+                            }
+                        }
+                        if (isu) { sm.du[lane] = s; o[lane] = s; }   // stage N has no input: 0
+                        else o[18 + (lane - 6)] = s;                 // DPI slot of stage k holds dpi_{k-1}
+                    } else if (lane < 30) {
+                        o[6 + (lane - 18)] = sm.dx[cur][lane - 18];
+                    }
+                });
+                if (k == Nl) break;
+                // W1: dx_{k+1}
+                ex.par([&](int lane) {
+                    if (lane < NX) {
+                        double v;
+                        if (lane < 6) v = sm.dx[cur][lane] + P.a12[lane] * sm.dx[cur][6 + lane] + P.b1[lane] * sm.du[lane];
+                        else v = P.a22[lane - 6] * sm.dx[cur][lane] + P.b2[lane - 6] * sm.du[lane - 6];
+                        sm.dx[nxt][lane] = v + vrb[(size_t)(k - k0) * WRB + lane];
+                    }
+                });
+                cur = nxt;
+            }
+            ex.par([&](int lane) {
+                double al = 1.0, a0 = 0, a1 = 0, a2 = 0;
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * NB; e += WAVE) {
+                    const int s = e / NB, j = e - s * NB, k = k0 + s;
+                    const bool hc = has_comp(Nl, k, j);
+                    const double *lt = vlt + (size_t)s * WLT, *r = vr + (size_t)s * WR;
+                    double *o = vo + (size_t)s * WO;
+                    const double dv = o[j];
+                    double dtl = 0, dll = 0, dtu = 0, dlu = 0;
+                    if (hc && bnd_lo(P, j) > -BOUND_INF) {
+                        const double l = lt[j], t = lt[24 + j];
+                        dtl = dv + r[j];
+                        dll = -(r[24 + j] + l * dtl) / t;
+                        if (dll < 0 && l + al * dll < 0) al = -l / dll;
+                        if (dtl < 0 && t + al * dtl < 0) al = -t / dtl;
+                        a0 += l * t; a1 += l * dtl + t * dll; a2 += dll * dtl;
+                    }
+                    if (hc && bnd_hi(P, j) < BOUND_INF) {
+                        const double l = lt[12 + j], t = lt[36 + j];
+                        dtu = -dv + r[12 + j];
+                        dlu = -(r[36 + j] + l * dtu) / t;
+                        if (dlu < 0 && l + al * dlu < 0) al = -l / dlu;
+                        if (dtu < 0 && t + al * dtu < 0) al = -t / dtu;
+                        a0 += l * t; a1 += l * dtu + t * dlu; a2 += dlu * dtu;
+                    }
+                    o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
+                    o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
+                }
+                sm.red[0][lane] = al; sm.red[1][lane] = a0; sm.red[2][lane] = a1; sm.red[3][lane] = a2;
+            });
+            alpha = fmin(alpha, ex.reduce_min(sm.red[0]));
+            s0 += ex.reduce_sum(sm.red[1]);
+            s1 += ex.reduce_sum(sm.red[2]);
+            s2 += ex.reduce_sum(sm.red[3]);
+            store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
+        }
+        S[0] = s0; S[1] = s1; S[2] = s2;
         PROF_ADD(PF_FWD, t0);
+        return alpha;
     }
 
     // =========================================================================== IPM driver
@@ -795,11 +917,10 @@ struct Engine {
     // Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
     MPC_HD int ipm_solve(int *iters_out)
     {
-        const double tol = c.sm->P.qp_tol;
-        const double nc = ipm_init();
-        double nrm[4];
-        double mu = ipm_residuals(nrm);
-        if (nc > 0) mu /= nc;
+        const double tol = ex.smem().P.qp_tol;
+        double nrm[4], smu = 0.0, nc = 0.0, S[3];
+        residual_pass(0, 0.0, nrm, &smu, &nc);
+        double mu = nc > 0 ? smu / nc : 0.0;
         int it = 0, status = 1;
         double alpha = 1.0;
         for (;; it++) {
@@ -807,24 +928,20 @@ struct Engine {
             if (!(nrm[0] > tol || nrm[1] > tol || nrm[2] > tol || nrm[3] > tol)) { status = 0; break; }
             if (it >= c.pb->qp_iter_max) { status = 1; break; }
             if (!(alpha > 1e-12)) { status = 2; break; }
-            riccati_backward<true>();
-            riccati_forward();
-            const double a_aff = ipm_step_lam_t();
+            fact_pass();
+            const double a_aff = forward_step_pass(S);
             if (nc > 0) {
-                const double mu_aff = ipm_mu_aff(a_aff) / nc;
+                const double mu_aff = (S[0] + a_aff * (S[1] + a_aff * S[2])) / nc;
                 const double tmp = mu_aff / mu;
                 const double sigma = tmp * tmp * tmp;
-                ipm_corrector_rhs(sigma * mu);
-                riccati_backward<false>();
-                riccati_forward();
-                alpha = ipm_step_lam_t();
+                corrector_bwd_pass(sigma * mu);
+                alpha = forward_step_pass(S);
             } else {
                 alpha = a_aff;
             }
             const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
-            ipm_update(a);
-            mu = ipm_residuals(nrm);
-            if (nc > 0) mu /= nc;
+            residual_pass(1, a, nrm, &smu, nullptr);
+            mu = nc > 0 ? smu / nc : 0.0;
         }
 #ifdef MPCB_PROFILE
         prof[PF_COUNT_IPM] += it;
@@ -833,164 +950,169 @@ struct Engine {
         return status;
     }
 
-    // =========================================================================== SQP / RTI
-    // x += alpha dx etc. (acados ocp_nlp_update_variables_sqp); multipliers blend for SQP.
-    MPC_HD void nlp_update(double alpha, bool blend_mult)
+    // =========================================================================== SQP line search
+    // One pass of the L1 merit function (acados ocp_nlp_evaluate_merit_fun restated) at the trial
+    // point (X,U) + alpha (dX,dU).  With `update_weights` the merit weights are first refreshed
+    // from the QP multipliers by Leineweber's rule (acados merit_backtracking_*_weights).
+    MPC_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
     {
         PROF_T0(t0);
-        Ws &w = c.w;
-        const int tx = (N + 1) * NX, tu = N * NU, tp = N * NX, tl = (N + 1) * NL;
-        ex.par([&](int lane) {
-            for (int e = lane; e < tx; e += WAVE) {
-                const int k = e / NX, i = e - k * NX;
-                w.X[e] += alpha * w.QW[(size_t)k * W_QW + 6 + i];
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const Robot &rb = sm.rb;
+        const int Nl = N;
+        constexpr int WMW = 36;
+        const int CH = chunk_len(W1 + WMW + 16, W1);
+        double total = 0.0;
+        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+            const int k1 = imin(k0 + CH - 1, Nl), hi = imin(k1 + 1, Nl);
+            double *v1 = ex.pool();                        // rows k0..hi, W1
+            double *vm = v1 + (size_t)(CH + 1) * W1;    // rows k0..k1, MW
+            double *vt = vm + (size_t)CH * WMW;         // rows k0..k1, scratch r(5)
+            load_rect<W1, 0, W1>(v1, c.w.G1, k0, hi);
+            load_rect<WMW, O_MW, W5>(vm, c.w.G5, k0, k1);
+            if (update_weights) {
+                ex.par([&](int lane) {
+                    const int rows = k1 - k0 + 1;
+                    for (int e = lane; e < rows * WMW; e += WAVE) {
+                        const int s = e / WMW, i = e - s * WMW;
+                        const double *r1 = v1 + (size_t)s * W1;
+                        const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
+                        double *mw = vm + (size_t)s * WMW + i;
+                        *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
+                    }
+                });
+                store_rect<WMW, O_MW, W5>(vm, c.w.G5, k0, k1);
             }
-            for (int e = lane; e < tu; e += WAVE) {
-                const int k = e / NU, i = e - k * NU;
-                w.U[e] += alpha * w.QW[(size_t)k * W_QW + i];
-            }
-            if (blend_mult) {
-                for (int e = lane; e < tp; e += WAVE) w.NPI[e] += alpha * (w.QPI[e] - w.NPI[e]);
-                for (int e = lane; e < tl; e += WAVE) {
-                    w.NLAM[e] += alpha * (w.QLAM[e] - w.NLAM[e]);
-                    w.NT[e] += alpha * (w.QT[e] - w.NT[e]);
+            ex.par([&](int lane) {
+                double acc = 0.0;
+                for (int k = k0 + lane; k <= k1; k += WAVE) {
+                    const double *r1 = v1 + (size_t)(k - k0) * W1, *rn = r1 + W1;
+                    const double *mw = vm + (size_t)(k - k0) * WMW;
+                    double xx[12], uu[6], rec[8];  // task_lin<false> only writes rec[O_R..O_R+4]
+#pragma unroll
+                    for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i] + alpha * r1[O_QW + 6 + i];
+                    if (k < Nl) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i] + alpha * r1[O_QW + i];
+                        task_lin<false>(rb, P, xx, xx + 6, rec);
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) s += P.w_task[i] * rec[O_R + i] * rec[O_R + i];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const double qdd = P.cq[j] * (uu[j] - xx[6 + j]);
+                            s += 2.0 * P.w_u * uu[j] * uu[j] + P.w_qddot * qdd * qdd;
+                            const double xnq = rn[O_X + j] + alpha * rn[O_QW + 6 + j];
+                            const double xnv = rn[O_X + 6 + j] + alpha * rn[O_QW + 12 + j];
+                            acc += mw[j] * fabs((xx[j] + P.a12[j] * xx[6 + j] + P.b1[j] * uu[j]) - xnq);
+                            acc += mw[6 + j] * fabs((P.a22[j] * xx[6 + j] + P.b2[j] * uu[j]) - xnv);
+                            const double vl = P.umin[j] - uu[j], vu = uu[j] - P.umax[j];
+                            if (vl > 0) acc += mw[12 + j] * vl;
+                            if (vu > 0) acc += mw[24 + j] * vu;
+                            if (k >= 1) {
+                                const double ql = P.qmin[j] - xx[j], qu = xx[j] - P.qmax[j];
+                                if (ql > 0) acc += mw[18 + j] * ql;
+                                if (qu > 0) acc += mw[30 + j] * qu;
+                            }
+                        }
+                        acc += 0.5 * P.dt * s;
+                    }
+                    if (k == 0) {
+#pragma unroll
+                        for (int i = 0; i < 12; i++) acc += c.w.state[13 + i] * fabs(sm.xhat[i] - xx[i]);
+                    }
                 }
-            }
-        });
-        PROF_ADD(PF_NUPD, t0);
+                (void)vt;
+                sm.red[0][lane] = acc;
+            });
+            total += ex.reduce_sum(sm.red[0]);
+        }
+        PROF_ADD(PF_MERIT, t0);
+        return total;
     }
 
-    // L1 merit function at (X,U) (acados ocp_nlp_evaluate_merit_fun restated).
-    MPC_HD double merit_fun(const double *X, const double *U)
+    // Merit weight of the eliminated x_0 constraint: |stage-0 stationarity of the QP wrt x_0|
+    MPC_PASS void update_x0_weights(int sqp_iter)
     {
-        Smem &sm = *c.sm;
-        const InstParams &P = sm.P;
-        Ws &w = c.w;
-        double m = linearize(X, U, false);
-        const int tb = N * NX, tc = (N + 1) * NB;
+        Smem &sm = ex.smem();
         ex.par([&](int lane) {
-            double s = 0.0;
-            for (int e = lane; e < tb; e += WAVE) {
-                const int k = e / NX, i = e - k * NX;
-                const double *x = X + (size_t)k * W_X, *u = U + (size_t)k * W_U, *xn = X + (size_t)(k + 1) * W_X;
+            if (lane < NX) {
+                const InstParams &P = sm.P;
+                const double *r1 = c.w.G1, *r2 = c.w.G2;  // stage 0 records in HBM (y holds W(r + G delta))
                 double v;
-                if (i < 6) v = (x[i] + P.a12[i] * x[6 + i] + P.b1[i] * u[i]) - xn[i];
-                else v = (P.a22[i - 6] * x[i] + P.b2[i - 6] * u[i - 6]) - xn[i];
-                s += w.MW[(size_t)k * W_MW + i] * fabs(v);
+                if (lane < 6) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + lane] * r2[O_Y + i];
+                    v = P.dt * s + r1[O_QPI + lane];
+                } else {
+                    const int jj = lane - 6;
+                    const double uj = r1[O_U + jj] + r1[O_QW + jj], vj = r1[O_X + 6 + jj] + r1[O_QW + 12 + jj];
+                    const double c2 = P.w_qddot * P.cq[jj] * P.cq[jj];
+                    v = P.dt * (r2[O_GV + jj] * r2[O_Y + 4] + c2 * (vj - uj)) + P.a12[jj] * r1[O_QPI + jj] +
+                        P.a22[jj] * r1[O_QPI + 6 + jj];
+                }
+                const double a = fabs(v);
+                double *mw = &c.w.state[13 + lane];
+                *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
             }
-            for (int e = lane; e < tc; e += WAVE) {
-                const int k = e / NB, j = e - k * NB;
-                if (!has_comp(N, k, j)) continue;
-                const double v = j < 6 ? U[k * W_U + j] : X[k * W_X + (j - 6)];
-                const double vl = bnd_lo(P, j) - v, vu = v - bnd_hi(P, j);
-                if (vl > 0) s += w.MW[(size_t)k * W_MW + 12 + j] * vl;
-                if (vu > 0) s += w.MW[(size_t)k * W_MW + 24 + j] * vu;
-            }
-            if (lane < NX) s += w.state[13 + lane] * fabs(sm.xhat[lane] - X[lane]);
-            sm.red[1][lane] = s;
         });
-        return m + ex.reduce_sum(sm.red[1]);
     }
 
     // MERIT_BACKTRACKING (trajectory_optimizer.py:68; acados alpha_reduction 0.7, alpha_min 0.05)
     MPC_HD double line_search(int sqp_iter)
     {
-        const InstParams &P = c.sm->P;
-        Ws &w = c.w;
-        const int tb = N * NX, tl = (N + 1) * NL;
-        phase_y(w.QW);
-        ex.par([&](int lane) {
-            for (int e = lane; e < tb; e += WAVE) {
-                const int k = e / NX, i = e - k * NX;
-                const double a = fabs(w.QPI[e]);
-                double *mw = &w.MW[(size_t)k * W_MW + i];
-                *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
-            }
-            for (int e = lane; e < tl; e += WAVE) {
-                const int k = e / NL, i = e - k * NL;
-                const double a = fabs(w.QLAM[e]);
-                double *mw = &w.MW[(size_t)k * W_MW + 12 + i];
-                *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
-            }
-            if (lane < NX) {
-                // multiplier of the eliminated x_0 constraint: stage-0 stationarity of the QP
-                const int j = lane;
-                double v;
-                if (j < 6) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NTASK; i++) s += w.RIC[RIC_GQ + i * 6 + j] * w.LIN[LIN_Y + i];
-                    v = P.dt * s + w.QPI[j];
-                } else {
-                    const int jj = j - 6;
-                    const double uj = w.U[jj] + w.QW[jj], vj = w.X[6 + jj] + w.QW[12 + jj];
-                    const double c2 = P.w_qddot * P.cq[jj] * P.cq[jj];
-                    v = P.dt * (w.RIC[RIC_GV + jj] * w.LIN[LIN_Y + 4] + c2 * (vj - uj)) + P.a12[jj] * w.QPI[jj] +
-                        P.a22[jj] * w.QPI[6 + jj];
-                }
-                const double a = fabs(v);
-                double *mw = &w.state[13 + lane];
-                *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
-            }
-        });
-        const double m0 = merit_fun(w.X, w.U);
+        update_x0_weights(sqp_iter);
+        const double m0 = merit_pass(0.0, true, sqp_iter);
         double alpha = 1.0;
-        const int tx = (N + 1) * NX, tu = N * NU;
         while (alpha >= 0.05) {
-            ex.par([&](int lane) {
-                for (int e = lane; e < tx; e += WAVE) {
-                    const int k = e / NX, i = e - k * NX;
-                    w.TX[e] = w.X[e] + alpha * w.QW[(size_t)k * W_QW + 6 + i];
-                }
-                for (int e = lane; e < tu; e += WAVE) {
-                    const int k = e / NU, i = e - k * NU;
-                    w.TU[e] = w.U[e] + alpha * w.QW[(size_t)k * W_QW + i];
-                }
-            });
-            if (merit_fun(w.TX, w.TU) < m0) break;
+            if (merit_pass(alpha, false, sqp_iter) < m0) break;
             alpha *= 0.7;
         }
         return alpha;
     }
 
     // One solver.solve() call (simulator.py:210-221).  On entry sm.xhat holds the feedback
-    // state and LIN/RIC/BD hold the linearisation at the current iterate when `lin_valid`.
-    // On exit they are valid for the (new) iterate again.
+    // state and G2 holds the linearisation at the current iterate when `lin_valid`; on exit it
+    // is valid for the (new) iterate again, together with its cost and NLP residuals.
     MPC_HD int nlp_step(bool &lin_valid, int *sqp_iter_out, int *qp_iter_out, double *res4, double *cost_out)
     {
         PROF_T0(t0);
-        Ws &w = c.w;
         int status = 0, sqp_iter = 0, qp_iter = 0, it = 0;
         double cost = lin_cost;
         if (c.pb->solver_type == 1) {
             // SQP_RTI: one linearisation, one QP, full step
-            if (!lin_valid) cost = linearize(w.X, w.U, true);
+            if (!lin_valid) cost = nlp_pass(0.0, false, false, nullptr);
             const int qs = ipm_solve(&it);
             qp_iter += it;
             sqp_iter = 1;
-            if (qs != 0 && qs != 1) status = 4;  // ACADOS_QP_FAILURE, iterate untouched
-            else nlp_update(1.0, false);
+            const bool ok = qs == 0 || qs == 1;
+            if (!ok) status = 4;  // ACADOS_QP_FAILURE, iterate untouched
             // residuals / cost are evaluated at the new iterate (acados get_residuals() for RTI,
             // get_cost()); this linearisation is reused by the next solve() call
-            cost = linearize(w.X, w.U, true);
+            cost = nlp_pass(1.0, ok, false, res4);
             lin_valid = true;
-            nlp_residuals(w.QPI, w.QLAM, w.QT, res4);
         } else {
-            const double tol = c.sm->P.tol;
+            const double tol = ex.smem().P.tol;
             status = 2;  // ACADOS_MAXITER unless decided otherwise
+            double alpha = 0.0;
+            bool pending = false;  // a step (alpha) waits to be applied by the next nlp_pass
             for (sqp_iter = 0; sqp_iter < c.pb->max_iter; sqp_iter++) {
-                if (!lin_valid) cost = linearize(w.X, w.U, true);
-                lin_valid = false;
-                nlp_residuals(w.NPI, w.NLAM, w.NT, res4);
-                if (res4[0] < tol && res4[1] < tol && res4[2] < tol && res4[3] < tol) { status = 0; lin_valid = true; break; }
+                if (pending || !lin_valid || sqp_iter == 0) {
+                    cost = nlp_pass(alpha, pending, true, res4);
+                    pending = false;
+                    lin_valid = true;
+                }
+                if (res4[0] < tol && res4[1] < tol && res4[2] < tol && res4[3] < tol) { status = 0; break; }
                 if (res4[0] != res4[0] || cost != cost) { status = 1; break; }
                 const int qs = ipm_solve(&it);
                 qp_iter += it;
                 if (qs != 0 && qs != 1) { status = 4; break; }
-                const double alpha = c.pb->fixed_step ? 1.0 : line_search(sqp_iter);
-                nlp_update(alpha, true);
+                alpha = c.pb->fixed_step ? 1.0 : line_search(sqp_iter);
+                pending = true;
             }
-            if (!lin_valid) { cost = linearize(w.X, w.U, true); lin_valid = true; }
+            if (pending) { cost = nlp_pass(alpha, true, true, nullptr); lin_valid = true; }  // max-iter exit: residuals of the last check stay
         }
         lin_cost = cost;
         *sqp_iter_out = sqp_iter;
@@ -1004,7 +1126,7 @@ struct Engine {
     // Simulator.run (simulator.py:199-241) for steps [step0, step1) of one instance.
     MPC_HD void rollout(const Outputs &out, int inst, int step0, int step1)
     {
-        Smem &sm = *c.sm;
+        Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         Ws &w = c.w;
         const int Nsim = c.pb->Nsim;
@@ -1014,12 +1136,12 @@ struct Engine {
             // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0 (SURVEY A.7 iv)
             const size_t tot = (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES;
             ex.par([&](int lane) {
-                for (size_t e = lane; e < tot; e += WAVE) w.X[e] = 0.0;  // X is the workspace base
+                for (size_t e = lane; e < tot; e += WAVE) w.G1[e] = 0.0;  // G1 is the workspace base
             });
             ex.par([&](int lane) {
                 for (int e = lane; e < (N + 1) * NX; e += WAVE) {
-                    const int i = e % NX;
-                    w.X[e] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
+                    const int k = e / NX, i = e - k * NX;
+                    w.G1[(size_t)k * W1 + O_X + i] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
                 }
                 if (lane < NX) sm.xhat[lane] = lane < 6 ? P.q0[lane] : P.qdot0[lane - 6];
                 if (lane < NU) sm.u0[lane] = P.qdot0[lane];  // u[:,0] = qdot_0 (simulator.py:81)
@@ -1043,7 +1165,7 @@ struct Engine {
             ex.par([&](int lane) {
                 if (lane < 6) {
                     const int j = lane;
-                    const double u = w.U[j], wc = P.wcv[j], dt = P.dt;
+                    const double u = w.G1[O_U + j], wc = P.wcv[j], dt = P.dt;
                     const double q = sm.xhat[j], v = sm.xhat[6 + j];
                     const double k1q = v, k1v = -wc * v + wc * u;
                     const double v2 = v + 0.5 * dt * k1v;
@@ -1087,9 +1209,9 @@ struct Engine {
     }
 
     // simulation_model.py:87-90: log state, input, FK pose, rpy, J*qdot at column `col`
-    MPC_HD void log_state(const Outputs &out, int inst, int col)
+    MPC_PASS void log_state(const Outputs &out, int inst, int col)
     {
-        Smem &sm = *c.sm;
+        Smem &sm = ex.smem();
         const Robot &rb = sm.rb;
         const int T1 = c.pb->Nsim + 1;
         ex.par([&](int lane) {

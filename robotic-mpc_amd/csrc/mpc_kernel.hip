@@ -23,8 +23,16 @@ static_assert(sizeof(mpcb_problem) == sizeof(Problem), "ABI struct mismatch");
 static_assert(sizeof(mpcb_result) == sizeof(Outputs), "ABI struct mismatch");
 static_assert(sizeof(Robot) == MPCB_NROBOT * sizeof(double), "robot layout");
 
+// LDS of the workgroup (= one wavefront = one simulation): fixed working set + chunk pool.
+__shared__ __attribute__((aligned(16))) Smem g_sm;
+extern __shared__ __attribute__((aligned(16))) double g_pool[];
+
+// Stateless on purpose: inside a non-inlined pass the executor is reached through `this`, and a
+// data member (e.g. a cached lane id) would be re-loaded from the stack at every phase.
 struct DevExec {
-    int lane;
+    __device__ __forceinline__ static int lane_id() { return (int)threadIdx.x; }
+    __device__ __forceinline__ Smem &smem() const { return g_sm; }
+    __device__ __forceinline__ double *pool() const { return g_pool; }
     // per-lane registers that live across phases (prefetched stage records)
     template <class T>
     struct PerLane {
@@ -34,27 +42,27 @@ struct DevExec {
     template <class F>
     __device__ __forceinline__ void par(F &&f)
     {
-        f(lane);
+        f(lane_id());
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ double reduce_sum(const double *r)
     {
-        double v = r[lane];
+        double v = r[lane_id()];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         return v;
     }
     __device__ __forceinline__ double reduce_max(const double *r)
     {
-        double v = r[lane];
+        double v = r[lane_id()];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
         return v;
     }
     __device__ __forceinline__ double reduce_min(const double *r)
     {
-        double v = r[lane];
+        double v = r[lane_id()];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
         return v;
@@ -65,14 +73,13 @@ struct DevExec {
 
 __global__ __launch_bounds__(WAVE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
                                                            double *ws_base, size_t ws_stride, Outputs out, int step0,
-                                                           int step1)
+                                                           int step1, int pool_doubles)
 {
-    __shared__ Smem sm;
     const int inst = blockIdx.x;
     if (inst >= pb.batch) return;
-    DevExec ex{(int)threadIdx.x};
-    load_constants(ex, sm, params + inst, &rb);
-    Ctx c{&pb, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), &sm, pb.N};
+    DevExec ex;
+    load_constants(ex, params + inst, &rb);
+    Ctx c{&pb, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), pool_doubles, pb.N};
     Engine<DevExec> eng(ex, c);
     eng.rollout(out, inst, step0, step1);
 }
@@ -90,6 +97,8 @@ struct mpcb_handle {
     double *d_ws = nullptr;
     size_t ws_cap = 0;
     size_t ws_stride = 0;
+    int pool_doubles = POOL_DEFAULT_DOUBLES;
+    int num_cus = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -141,6 +150,11 @@ int mpcb_create(mpcb_handle **out, int device)
     mpcb_handle *h = new (std::nothrow) mpcb_handle;
     if (!h) return MPCB_ENOMEM;
     h->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->num_cus = prop.multiProcessorCount;
+    }
     if (hipSetDevice(device) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) {
         delete h;
@@ -211,6 +225,18 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         if (hipMalloc((void **)&h->d_ws, wbytes) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(workspace)");
         h->ws_cap = wbytes;
     }
+    // LDS chunk pool: the whole 160 KiB of a CU is shared by the waves resident on it, so size the
+    // pool for the number of simulations per CU this batch implies (1 for batch <= #CUs).
+    {
+        const int wpc = (p->batch + h->num_cus - 1) / h->num_cus;
+        const int lds_total = 160 * 1024, fixed = (int)sizeof(Smem) + 1024;
+        int bytes = lds_total / (wpc < 1 ? 1 : (wpc > 8 ? 8 : wpc)) - fixed;
+        if (bytes > POOL_DEFAULT_DOUBLES * 8) bytes = POOL_DEFAULT_DOUBLES * 8;
+        if (bytes < POOL_MIN_DOUBLES * 8) bytes = POOL_MIN_DOUBLES * 8;
+        h->pool_doubles = (bytes / 16) * 2;
+        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      h->pool_doubles * (int)sizeof(double)));
+    }
     h->ready = true;
     h->next_step = 0;
     h->timed = false;
@@ -233,8 +259,8 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     Outputs out;
     std::memcpy(&out, o, sizeof out);
     HIPCHK(h, hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(mpc_rollout_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), 0, s, h->pb, h->rb, h->d_params,
-                       h->d_ws, h->ws_stride, out, step0, step1);
+    hipLaunchKernelGGL(mpc_rollout_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), (size_t)h->pool_doubles * sizeof(double), s,
+                       h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out, step0, step1, h->pool_doubles);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, s));
     h->last_stream = s;

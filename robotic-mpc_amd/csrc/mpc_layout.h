@@ -1,17 +1,28 @@
 // mpc_layout.h -- data layout of the batched MPC rollout engine (gfx950).
 //
-// One wavefront (64 lanes) owns one simulation instance.  All per-instance solver
-// state lives in an HBM workspace laid out STAGE-MAJOR: for every array the record of
-// stage k is contiguous, so (a) the sequential Riccati sweeps read/write one stage's
-// K/P/Rinv blocks with fully coalesced wave accesses and (b) the element-wise IPM
-// phases walk the flat arrays with lane-contiguous addresses.
+// One wavefront (64 lanes) owns one simulation instance.  All per-instance solver state
+// lives in an HBM workspace, STAGE-MAJOR, split into five record groups so that every pass of
+// the solver streams whole contiguous stage records:
+//     G1 ITER  iterate + QP iterate      G2 LINR  linearisation + Newton right-hand sides
+//     G3 STEP  residuals + Newton step   G4 FACT  Riccati factor (K, R^-1, h_u, p, P)
+//     G5 SQPX  SQP-only extras (NLP multipliers, trial point, merit weights)
+// A pass copies a CHUNK of consecutive stages HBM -> LDS in one coalesced burst (16 B per
+// lane, all loads in flight together), works on the chunk entirely in LDS -- the sequential
+// Riccati recursions never touch HBM inside the stage loop -- and writes its outputs back in
+// one burst.  This matters on gfx950 because a `s_waitcnt vmcnt` that covers a store costs
+// ~1 us (stores are acknowledged from the memory side), so per-stage loads/stores would
+// serialise the whole recursion on memory latency.
 //
-// Reference being replaced: simulator.py:199-241 (Simulator.run) and the acados /
-// HPIPM solver behind trajectory_optimizer.py:183-186.
+// Reference being replaced: simulator.py:199-241 (Simulator.run) and the acados / HPIPM
+// solver behind trajectory_optimizer.py:183-186.
 #pragma once
 
+#include <stddef.h>
+
 #define MPC_HD __host__ __device__ __forceinline__
-#define MPC_HDN __host__ __device__ __noinline__
+// a solver pass: its own function (own register allocation) so the kernel does not become one
+// giant inlined body that the register allocator spills
+#define MPC_PASS __host__ __device__ __noinline__
 
 namespace mpcb {
 
@@ -24,37 +35,43 @@ constexpr int NB = 12;  // bounded components per stage: u (6) then q (6)
 constexpr int NL = 24;  // multipliers / slacks per stage: lower (12) then upper (12)
 constexpr int NTASK = 5;
 
-// ---- per-stage record widths (doubles) ------------------------------------------
-constexpr int W_X = 12;
-constexpr int W_U = 6;
-constexpr int W_QW = 18;    // QP primal [du; dq; dqdot]
-constexpr int W_PI = 12;
-constexpr int W_LAM = 24;
-constexpr int W_T = 24;
-constexpr int W_LIN = 16;   // [0..4] r = g - gref, [5..9] y = W (r + G delta), pad
-constexpr int W_RIC = 80;   // everything the factorisation sweep reads for one stage, contiguous:
-                            // [0..29] Gq (5x6), [30..35] gv5, [36..47] Gamma, [48..65] gt, [66..77] rb
-constexpr int W_BD = 12;    // dynamics defect of the NLP iterate
-constexpr int W_RG = 18;
-constexpr int W_RD = 24;
-constexpr int W_RM = 24;
-constexpr int W_DW = 18;
-constexpr int W_DPI = 12;
-constexpr int W_DLAM = 24;
-constexpr int W_DT = 24;
-constexpr int W_FAC = 128;  // what the solve sweeps read for one stage, contiguous:
-                            // [0..71] Kfb = R^-1 S (6x12), [72..107] R^-1 (6x6), [108..113] h_u, [114..125] p_k
-constexpr int W_PM = 144;   // cost-to-go matrix P_k (12x12, full)
-constexpr int W_MW = 36;    // merit weights: dyn (12) + ineq (24)    (SQP only)
+// ---- G1 ITER ----------------------------------------------------------------------
+constexpr int W1 = 96;
+constexpr int O_X = 0, O_U = 12, O_QW = 18, O_QPI = 36, O_QLAM = 48, O_QT = 72;
+// ---- G2 LINR ----------------------------------------------------------------------
+constexpr int W2 = 112;
+constexpr int O_R = 0;     // r = g - g_ref (5)
+constexpr int O_Y = 5;     // y = W (r + G delta) (5)
+constexpr int O_BD = 12;   // dynamics defect of the NLP iterate (12)
+constexpr int O_GQ = 24;   // d g / d q (5x6)
+constexpr int O_GV = 54;   // d g5 / d qdot (6)
+constexpr int O_GAM = 60;  // Gamma = lam/t (12)
+constexpr int O_GT = 72;   // condensed gradient of the Newton system (18)
+constexpr int O_RB = 90;   // dynamics residual of the QP iterate (12)
+constexpr int W2_LIN = 60;   // [R..GV]: what a linearisation produces
+constexpr int W2_USED = 102;  // [R..RB]
+// ---- G3 STEP ----------------------------------------------------------------------
+constexpr int W3 = 144;
+constexpr int O_RG = 0, O_RD = 18, O_RM = 42;  // residuals g (18), d (24), m (24)
+constexpr int O_DW = 66;    // Newton step [du; dq; dqdot] (18)
+constexpr int O_DPI = 84;   // step of the multiplier of dynamics k-1 -> k (12)   (note the shift)
+constexpr int O_DLAM = 96, O_DT = 120;
+// ---- G4 FACT ----------------------------------------------------------------------
+constexpr int W4 = 272;
+constexpr int O_K = 0;      // Kfb = R~^-1 S~ (6x12)
+constexpr int O_RI = 72;    // R~^-1 (6x6)
+constexpr int O_HU = 108;   // h_u (6)
+constexpr int O_PV = 114;   // p_k (12)
+constexpr int O_PM = 128;   // P_k (12x12)
+// ---- G5 SQPX ----------------------------------------------------------------------
+constexpr int W5 = 116;
+constexpr int O_NPI = 0, O_NLAM = 12, O_NT = 36, O_TX = 60, O_TU = 72, O_MW = 78;  // MW: dyn 12 + ineq 24
 
-constexpr int LIN_R = 0, LIN_Y = 5;
-constexpr int RIC_GQ = 0, RIC_GV = 30, RIC_GAM = 36, RIC_GT = 48, RIC_RB = 66;
-constexpr int FAC_K = 0, FAC_RI = 72, FAC_HU = 108, FAC_PV = 114;
-
-constexpr int STAGE_DOUBLES = W_X + W_U + W_QW + W_PI + W_LAM + W_T + W_LIN + W_RIC + W_BD + W_RG + W_RD + W_RM +
-                              W_DW + W_DPI + W_DLAM + W_DT + W_FAC + W_PM +
-                              /* NLP multipliers + trial iterate + merit weights (SQP) */
-                              W_PI + W_LAM + W_T + W_X + W_U + W_MW;
+constexpr int STAGE_DOUBLES = W1 + W2 + W3 + W4 + W5;
+// [0..11] plant state z, [12] cost of the held linearisation, [13..24] merit weights of the x0
+// constraint, [25] linearisation-valid flag, [32..47] profile counters (diagnostic build)
+constexpr int STATE_DOUBLES = 64;
+constexpr int NPROF = 16;
 
 // Kinematic constants (robots.py KinematicChain.packed): 105 doubles
 struct Robot {
@@ -63,7 +80,7 @@ struct Robot {
     double t_ee[3];       // prediction_model.py:9
 };
 
-// Per-instance parameters, one record per instance in HBM (packed by mpcb_pack_params).
+// Per-instance parameters, one record per instance in HBM (packed by pack_inst_params).
 struct InstParams {
     double dt, tol, qp_tol, w_u, w_qddot, px_ref, vy_ref, pad0;
     double wcv[6], q0[6], qdot0[6], qmin[6], qmax[6], umin[6], umax[6];
@@ -75,7 +92,7 @@ struct InstParams {
     double cq[6];       // qddot gain (1-a22)/Ts
 };
 
-// Batch-uniform problem description.
+// Batch-uniform problem description (== mpcb_problem).
 struct Problem {
     int batch;
     int N;            // prediction_horizon
@@ -87,8 +104,8 @@ struct Problem {
     int pad;
 };
 
-// Device pointers to the result logs, batch-major, same per-instance shapes as the
-// reference's logs (simulation_model.py:25-29, simulator.py:59-65).
+// Device pointers to the result logs (== mpcb_result), batch-major, per-instance shapes of
+// the reference's logs (simulation_model.py:25-29, simulator.py:59-65).
 struct Outputs {
     double *z;         // [batch][12][Nsim+1]
     double *u;         // [batch][6][Nsim+1]
@@ -103,74 +120,48 @@ struct Outputs {
     double *solver_time; // [batch][Nsim] seconds (device realtime counter)
 };
 
-// Views into one instance's workspace.
+// One instance's workspace: five stage-major group arrays + persistent scalars.
 struct Ws {
-    double *X, *U, *QW, *QPI, *QLAM, *QT, *LIN, *RIC, *BD, *RG, *RD, *RM, *DW, *DPI, *DLAM, *DT, *FAC, *PM;
-    double *NPI, *NLAM, *NT, *TX, *TU, *MW;  // SQP extras
-    double *state;                           // persistent scalars between launches
+    double *G1, *G2, *G3, *G4, *G5, *state;
 };
 
-// [0..11] plant state z, [12] cost of the held linearisation, [13..24] merit weights of the
-// x0 constraint, [25] linearisation-valid flag, [32..47] profile counters (diagnostic build)
-constexpr int STATE_DOUBLES = 64;
-constexpr int NPROF = 16;
-
-MPC_HD size_t ws_doubles_per_instance(int N)
-{
-    return (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES;
-}
+MPC_HD size_t ws_doubles_per_instance(int N) { return (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES; }
 
 MPC_HD Ws ws_carve(double *base, int N)
 {
     const size_t n1 = (size_t)N + 1;
     Ws w;
     double *p = base;
-    w.X = p; p += n1 * W_X;
-    w.U = p; p += n1 * W_U;
-    w.QW = p; p += n1 * W_QW;
-    w.QPI = p; p += n1 * W_PI;
-    w.QLAM = p; p += n1 * W_LAM;
-    w.QT = p; p += n1 * W_T;
-    w.LIN = p; p += n1 * W_LIN;
-    w.RIC = p; p += n1 * W_RIC;
-    w.BD = p; p += n1 * W_BD;
-    w.RG = p; p += n1 * W_RG;
-    w.RD = p; p += n1 * W_RD;
-    w.RM = p; p += n1 * W_RM;
-    w.DW = p; p += n1 * W_DW;
-    w.DPI = p; p += n1 * W_DPI;
-    w.DLAM = p; p += n1 * W_DLAM;
-    w.DT = p; p += n1 * W_DT;
-    w.FAC = p; p += n1 * W_FAC;
-    w.PM = p; p += n1 * W_PM;
-    w.NPI = p; p += n1 * W_PI;
-    w.NLAM = p; p += n1 * W_LAM;
-    w.NT = p; p += n1 * W_T;
-    w.TX = p; p += n1 * W_X;
-    w.TU = p; p += n1 * W_U;
-    w.MW = p; p += n1 * W_MW;
+    w.G1 = p; p += n1 * W1;
+    w.G2 = p; p += n1 * W2;
+    w.G3 = p; p += n1 * W3;
+    w.G4 = p; p += n1 * W4;
+    w.G5 = p; p += n1 * W5;
     w.state = p;
     return w;
 }
 
-// LDS working set of one wavefront (one instance).
-constexpr int STG_DOUBLES = 2 * 288;  // two staging buffers
+// Static LDS working set of one wavefront; the chunk pool follows it (dynamic LDS).
 struct Smem {
     InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
     Robot rb;
-    double stg[STG_DOUBLES];  // stage record prefetched from HBM one stage ahead of the sweeps
     double M[2][144];   // P_{k+1} / P_k double buffer during the factorisation sweep
     double pv[2][12];
     double Rt[36];      // R~ = H_uu + Gamma_u + B'MB
     double St[72];      // S~ = H_ux + B'MA           (6x12)
     double Kf[72];      // R~^-1 S~
     double mt[12];      // p_{k+1} + P_{k+1} rb_k
+    double hx[12];      // h_x
     double dx[2][12];
     double du[6];
-    double red[5][WAVE];
+    double red[8][WAVE];
     double xhat[12];    // current plant state (feedback, simulator.py:206)
     double u0[6];
     double logv[40];
 };
+
+// Chunk pool sizes (doubles).  The widest pass needs ~500 doubles per stage (+1 halo stage).
+constexpr int POOL_MIN_DOUBLES = 2048;
+constexpr int POOL_DEFAULT_DOUBLES = 16384;  // 128 KiB: one wave per CU (batch <= 256 per GPU)
 
 }  // namespace mpcb

@@ -22,7 +22,7 @@ def build(force=False):
     return _LIB
 
 
-def run(cfgs, chain, step_chunk=0):
+def run(cfgs, chain, step_chunk=0, pool_doubles=0):
     """cfgs: list of resolved configs sharing one bucket. Returns dict of arrays [batch, ...]."""
     from robotic_mpc_amd import packing
 
@@ -46,6 +46,7 @@ def run(cfgs, chain, step_chunk=0):
     for k in ("residuals", "cost", "solver_time"):
         args.append(o[k].ctypes.data_as(dp))
     args.append(C.c_int(step_chunk))
+    args.append(C.c_int(pool_doubles))
     rc = lib.emu_run(*args)
     assert rc == 0
     return o

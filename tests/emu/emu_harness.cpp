@@ -17,6 +17,10 @@
 using namespace mpcb;
 
 struct HostExec {
+    Smem *sm_;
+    double *pool_;
+    Smem &smem() const { return *sm_; }
+    double *pool() const { return pool_; }
     template <class T>
     struct PerLane {
         T v[WAVE];
@@ -36,7 +40,7 @@ struct HostExec {
 extern "C" int emu_run(const Problem *pb, const double *robot105, const double *params /* [batch][MPCB_NPARAM] */,
                        double *z, double *u, double *ee_pose, double *ee_rpy, double *ee_vel, int *status,
                        int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time,
-                       int step_chunk)
+                       int step_chunk, int pool_doubles)
 {
     Robot rb;
     std::memcpy(&rb, robot105, sizeof(Robot));
@@ -48,11 +52,13 @@ extern "C" int emu_run(const Problem *pb, const double *robot105, const double *
         pack_inst_params(params + (size_t)inst * MPCB_NPARAM, &P);
         Smem sm;
         std::memset(&sm, 0, sizeof sm);
-        HostExec ex;
+        if (pool_doubles <= 0) pool_doubles = POOL_DEFAULT_DOUBLES;
+        std::vector<double> pool((size_t)pool_doubles + 64, 0.0);
+        HostExec ex{&sm, pool.data()};
         if (step_chunk <= 0) step_chunk = pb->Nsim;
         for (int s0 = 0; s0 < pb->Nsim; s0 += step_chunk) {
-            load_constants(ex, sm, &P, &rb);
-            Ctx c{pb, ws_carve(ws.data(), pb->N), &sm, pb->N};
+            load_constants(ex, &P, &rb);
+            Ctx c{pb, ws_carve(ws.data(), pb->N), pool_doubles, pb->N};
             Engine<HostExec> eng(ex, c);
             const int s1 = s0 + step_chunk < pb->Nsim ? s0 + step_chunk : pb->Nsim;
             eng.rollout(out, inst, s0, s1);

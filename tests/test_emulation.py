@@ -23,14 +23,18 @@ def _cfg(**kw):
     return config.resolve_config(config.base_params(**kw))
 
 
-@pytest.mark.parametrize("N,T,solver,chunk", [(20, 0.6, "SQP_RTI", 0), (20, 0.3, "SQP", 0), (1, 0.1, "SQP_RTI", 0),
-                                               (2, 0.1, "SQP", 0), (65, 0.2, "SQP_RTI", 7), (130, 0.05, "SQP_RTI", 0)])
-def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk):
+# pool = LDS chunk pool in doubles: 2048 forces chunks of 3-7 stages (many chunk seams and halos),
+# 0 = the default 128 KiB pool (one or two chunks)
+@pytest.mark.parametrize("N,T,solver,chunk,pool", [
+    (20, 0.6, "SQP_RTI", 0, 0), (20, 0.3, "SQP", 0, 0), (1, 0.1, "SQP_RTI", 0, 0), (2, 0.1, "SQP", 0, 2048),
+    (65, 0.2, "SQP_RTI", 7, 0), (130, 0.05, "SQP_RTI", 0, 0), (23, 0.3, "SQP_RTI", 0, 2048), (11, 0.2, "SQP", 3, 2048),
+    (100, 0.05, "SQP_RTI", 0, 4096)])
+def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk, pool):
     import emu
 
     cfg = _cfg(prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
     ref = orc.run(ur10_rb, orc.make_params(cfg))
-    out = emu.run([cfg], ur10, step_chunk=chunk)
+    out = emu.run([cfg], ur10, step_chunk=chunk, pool_doubles=pool)
     for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
         np.testing.assert_allclose(out[k][0], ref[k], atol=1e-11, rtol=0, err_msg=k)
     np.testing.assert_allclose(out["cost"][0], ref["cost"], atol=1e-10, rtol=1e-10)
