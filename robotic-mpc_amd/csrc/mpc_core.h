@@ -70,6 +70,20 @@ MPC_HD double bnd_hi(const InstParams &P, int j) { return j < 6 ? P.umax[j] : P.
 MPC_HD int imin(int a, int b) { return a < b ? a : b; }
 MPC_HD int imax(int a, int b) { return a > b ? a : b; }
 
+// 1/d for the LDL' pivots: hardware reciprocal seed + two Newton steps (full fp64 accuracy to an
+// ulp or two) instead of the ~40-instruction IEEE division on the sequential critical path.
+MPC_HD double fast_rcp(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+#else
+    return 1.0 / d;
+#endif
+}
+
 // lower-triangle index e -> (i, j), i >= j
 MPC_HD void tri_index(int e, int &i, int &j)
 {
@@ -535,6 +549,83 @@ struct Engine {
     }
 
     // =========================================================================== Riccati passes
+    // A lane's work items in the factorisation sweep are the same for every stage, so the index
+    // decoding and the products of model constants are hoisted out of the stage loop into
+    // per-lane registers.  Item = sum_t coef[t] * M[off[t]] + cst.
+    struct Item4 {
+        double coef[4];
+        double cst;
+        int off[4];
+    };
+    struct FactLane {
+        Item4 s1;        // S~ entry e = lane                         (every lane)
+        Item4 x2;        // lanes 0..7: S~ entry 64+lane ; lanes 8..28: R~ entry lane-8
+        int x2_dst;      // LDS destination of x2 (index into St, or into Rt with bit 30 set)
+        int x2_gam;      // Gamma_u index added to x2 (diagonal R~ entries), -1 otherwise
+        int x2_mirror;   // mirrored Rt destination, -1 otherwise
+        Item4 p1, p2;    // A'MA parts of P entries e = lane and (lanes 0..13) 64 + lane
+        int pi1, pj1, pi2, pj2;   // their (i, j), i >= j
+        double pc1, pc2; // constant parts of H_xx for them (dt*w*c^2 on the vv diagonal)
+        int pg1, pg2;    // Gamma_q index on the qq diagonal, -1 otherwise
+    };
+
+    MPC_HD static void s_item(const InstParams &P, int e, Item4 &it)
+    {
+        const int m = e / 12, cc = e - m * 12;
+        if (cc < 6) {
+            it.coef[0] = P.b1[m]; it.off[0] = m * 12 + cc;
+            it.coef[1] = P.b2[m]; it.off[1] = (6 + m) * 12 + cc;
+            it.coef[2] = 0.0; it.off[2] = 0;
+            it.coef[3] = 0.0; it.off[3] = 0;
+            it.cst = 0.0;
+        } else {
+            const int j = cc - 6;
+            it.coef[0] = P.b1[m] * P.a12[j]; it.off[0] = m * 12 + j;
+            it.coef[1] = P.b2[m] * P.a12[j]; it.off[1] = (6 + m) * 12 + j;
+            it.coef[2] = P.b1[m] * P.a22[j]; it.off[2] = m * 12 + 6 + j;
+            it.coef[3] = P.b2[m] * P.a22[j]; it.off[3] = (6 + m) * 12 + 6 + j;
+            it.cst = m == j ? -(P.dt * P.w_qddot * P.cq[j] * P.cq[j]) : 0.0;
+        }
+    }
+    MPC_HD static void r_item(const InstParams &P, int e, Item4 &it, int &i, int &j)
+    {
+        tri_index(e, i, j);
+        it.coef[0] = P.b1[i] * P.b1[j]; it.off[0] = i * 12 + j;
+        it.coef[1] = P.b2[i] * P.b1[j]; it.off[1] = (6 + i) * 12 + j;
+        it.coef[2] = P.b1[i] * P.b2[j]; it.off[2] = i * 12 + 6 + j;
+        it.coef[3] = P.b2[i] * P.b2[j]; it.off[3] = (6 + i) * 12 + 6 + j;
+        it.cst = i == j ? P.dt * (2.0 * P.w_u + P.w_qddot * P.cq[i] * P.cq[i]) : 0.0;
+    }
+    // A'MA part of P(i,j), i >= j
+    MPC_HD static void p_item(const InstParams &P, int e, Item4 &it, int &i, int &j, double &cst, int &gam)
+    {
+        tri_index(e, i, j);
+        cst = 0.0; gam = -1;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { it.coef[t] = 0.0; it.off[t] = 0; }
+        it.cst = 0.0;
+        if (i < 6) {
+            it.coef[0] = 1.0; it.off[0] = i * 12 + j;
+            if (i == j) gam = 6 + i;
+        } else if (j < 6) {
+            const int a = i - 6, b = j;
+            it.coef[0] = P.a12[a]; it.off[0] = a * 12 + b;
+            it.coef[1] = P.a22[a]; it.off[1] = (6 + a) * 12 + b;
+        } else {
+            const int a = i - 6, b = j - 6;
+            it.coef[0] = P.a12[a] * P.a12[b]; it.off[0] = a * 12 + b;
+            it.coef[1] = P.a22[a] * P.a12[b]; it.off[1] = (6 + a) * 12 + b;
+            it.coef[2] = P.a12[a] * P.a22[b]; it.off[2] = a * 12 + 6 + b;
+            it.coef[3] = P.a22[a] * P.a22[b]; it.off[3] = (6 + a) * 12 + 6 + b;
+            if (a == b) cst = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
+        }
+    }
+    MPC_HD static double eval_item(const Item4 &it, const double *M)
+    {
+        return it.coef[0] * M[it.off[0]] + it.coef[1] * M[it.off[1]] + it.coef[2] * M[it.off[2]] +
+               it.coef[3] * M[it.off[3]] + it.cst;
+    }
+
     // Factorisation sweep (backward over chunks): per stage rebuild (R~, S~, P) from Gamma and the
     // Jacobians, Kfb = R~^-1 S~, R~^-1, P_k, and propagate the vector part (gt, rb) -> p_k, h_u.
     MPC_PASS void fact_pass()
@@ -545,10 +636,31 @@ struct Engine {
         const int Nl = N;
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12)
         const int CH = chunk_len(WR + W4, 0);
+        typename Ex::template PerLane<FactLane> fl;
+        ex.par([&](int lane) {
+            FactLane &f = fl.at(lane);
+            s_item(P, lane, f.s1);
+            f.x2_dst = -1; f.x2_gam = -1; f.x2_mirror = -1;
+            if (lane < 8) {
+                s_item(P, 64 + lane, f.x2);
+                f.x2_dst = 64 + lane;
+            } else if (lane < 29) {
+                int i, j;
+                r_item(P, lane - 8, f.x2, i, j);
+                f.x2_dst = (1 << 30) | (i * 6 + j);
+                f.x2_mirror = j * 6 + i;
+                f.x2_gam = i == j ? i : -1;
+            } else {
+                s_item(P, lane, f.x2);  // unused, keeps the registers defined
+            }
+            p_item(P, lane, f.p1, f.pi1, f.pj1, f.pc1, f.pg1);
+            p_item(P, lane < 14 ? 64 + lane : lane, f.p2, f.pi2, f.pj2, f.pc2, f.pg2);
+        });
+        const double dtw5 = P.dt * P.w_task[4];
         int cur = 0;
         for (int k1 = Nl; k1 >= 0; k1 -= CH) {
             const int k0 = imax(k1 - CH + 1, 0);
-            double *vr = ex.pool();                   // rows k0..k1, 78: GQ 0, GV 30, GAM 36, GT 48, RB 66
+            double *vr = ex.pool();                // rows k0..k1, 78: GQ 0, GV 30, GAM 36, GT 48, RB 66
             double *vf = vr + (size_t)CH * WR;     // rows k0..k1, W4
             load_rect<WR, O_GQ, W2>(vr, c.w.G2, k0, k1);
             for (int k = k1; k >= k0; k--) {
@@ -564,40 +676,22 @@ struct Engine {
                     });
                     continue;
                 }
-                // ---- F0: R~ (21 lower entries), S~ (72), m~ = p_{k+1} + P_{k+1} rb_k (12)
+                // ---- F0: S~ (72 entries), R~ (21 lower entries), m~ = p_{k+1} + P_{k+1} rb_k (12)
                 ex.par([&](int lane) {
                     const double *M = sm.M[cur];
-                    if (lane < 21) {
-                        int i, j;
-                        tri_index(lane, i, j);
-                        double r = P.b1[i] * P.b1[j] * M[i * 12 + j] + P.b2[i] * P.b1[j] * M[(6 + i) * 12 + j] +
-                                   P.b1[i] * P.b2[j] * M[i * 12 + 6 + j] + P.b2[i] * P.b2[j] * M[(6 + i) * 12 + 6 + j];
-                        if (i == j) {
-                            const double c2 = P.w_qddot * P.cq[i] * P.cq[i];
-                            r += P.dt * (2.0 * P.w_u + c2) + gam[i];
-                        }
-                        sm.Rt[i * 6 + j] = r;
-                        sm.Rt[j * 6 + i] = r;
-                    }
-                    for (int e = lane; e < 72; e += WAVE) {
-                        const int m = e / 12, cc = e - m * 12;
-                        double s;
-                        if (cc < 6) {
-                            s = P.b1[m] * M[m * 12 + cc] + P.b2[m] * M[(6 + m) * 12 + cc];
-                        } else {
-                            const int j = cc - 6;
-                            const double fq = P.b1[m] * M[m * 12 + j] + P.b2[m] * M[(6 + m) * 12 + j];
-                            const double fv = P.b1[m] * M[m * 12 + 6 + j] + P.b2[m] * M[(6 + m) * 12 + 6 + j];
-                            s = fq * P.a12[j] + fv * P.a22[j];
-                            if (m == j) s -= P.dt * P.w_qddot * P.cq[j] * P.cq[j];
-                        }
-                        sm.St[e] = s;
-                    }
-                    if (lane < NX) {
-                        double s = sm.pv[cur][lane];
+                    const FactLane &f = fl.at(lane);
+                    sm.St[lane] = eval_item(f.s1, M);
+                    if (lane < 29) {
+                        double v = eval_item(f.x2, M);
+                        if (f.x2_gam >= 0) v += gam[f.x2_gam];
+                        if (lane < 8) sm.St[f.x2_dst] = v;
+                        else { sm.Rt[f.x2_dst & 0xffff] = v; sm.Rt[f.x2_mirror] = v; }
+                    } else if (lane >= 32 && lane < 32 + NX) {
+                        const int i = lane - 32;
+                        double s = sm.pv[cur][i];
 #pragma unroll
-                        for (int j = 0; j < NX; j++) s += M[lane * 12 + j] * rbv[j];
-                        sm.mt[lane] = s;
+                        for (int j = 0; j < NX; j++) s += M[i * 12 + j] * rbv[j];
+                        sm.mt[i] = s;
                     }
                 });
                 // ---- F1: LDL' of R~ (redundant), one right-hand side per lane; vector part
@@ -612,7 +706,7 @@ struct Engine {
 #pragma unroll
                         for (int r = 0; r < j; r++) d -= L[j][r] * L[j][r] * dd[r];
                         dd[j] = d;
-                        dinv[j] = 1.0 / d;
+                        dinv[j] = fast_rcp(d);
 #pragma unroll
                         for (int i = j + 1; i < 6; i++) {
                             double s = sm.Rt[i * 6 + j];
@@ -663,36 +757,28 @@ struct Engine {
                 ex.par([&](int lane) {
                     const double *M = sm.M[cur];
                     const double *gq = ric, *gv = ric + 30;
-                    if (lane < NX) {
-                        double pj = sm.hx[lane];
+                    const FactLane &f = fl.at(lane);
+                    if (lane >= 32 && lane < 32 + NX) {
+                        const int i = lane - 32;
+                        double pj = sm.hx[i];
 #pragma unroll
-                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + lane] * fac[O_HU + m];
-                        sm.pv[nxt][lane] = pj;
-                        fac[O_PV + lane] = pj;
+                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + i] * fac[O_HU + m];
+                        sm.pv[nxt][i] = pj;
+                        fac[O_PV + i] = pj;
                     }
                     if (k > 0) {
-                        for (int e = lane; e < 78; e += WAVE) {
-                            int i, j;
-                            tri_index(e, i, j);
-                            double v;
-                            if (i < 6) {  // qq
-                                v = M[i * 12 + j];
+                        auto entry = [&](const Item4 &it, int i, int j, double cst, int gi) {
+                            double v = eval_item(it, M) + cst;
+                            if (i < 6) {
                                 double s = 0.0;
 #pragma unroll
                                 for (int r = 0; r < NTASK; r++) s += P.w_task[r] * gq[r * 6 + i] * gq[r * 6 + j];
                                 v += P.dt * s;
-                                if (i == j) v += gam[6 + i];
-                            } else if (j < 6) {  // vq: row 6+a, col b
-                                const int a = i - 6, b = j;
-                                v = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
-                                v += P.dt * P.w_task[4] * gv[a] * gq[4 * 6 + b];
-                            } else {  // vv
-                                const int a = i - 6, b = j - 6;
-                                const double cq = P.a12[a] * M[a * 12 + b] + P.a22[a] * M[(6 + a) * 12 + b];
-                                const double cv = P.a12[a] * M[a * 12 + 6 + b] + P.a22[a] * M[(6 + a) * 12 + 6 + b];
-                                v = cq * P.a12[b] + cv * P.a22[b];
-                                v += P.dt * P.w_task[4] * gv[a] * gv[b];
-                                if (a == b) v += P.dt * P.w_qddot * P.cq[a] * P.cq[a];
+                                if (gi >= 0) v += gam[gi];
+                            } else if (j < 6) {
+                                v += dtw5 * gv[i - 6] * gq[24 + j];
+                            } else {
+                                v += dtw5 * gv[i - 6] * gv[j - 6];
                             }
 #pragma unroll
                             for (int m = 0; m < 6; m++) v -= sm.St[m * 12 + i] * sm.Kf[m * 12 + j];
@@ -700,7 +786,9 @@ struct Engine {
                             sm.M[nxt][j * 12 + i] = v;
                             fac[O_PM + i * 12 + j] = v;
                             fac[O_PM + j * 12 + i] = v;
-                        }
+                        };
+                        entry(f.p1, f.pi1, f.pj1, f.pc1, f.pg1);
+                        if (lane < 14) entry(f.p2, f.pi2, f.pj2, f.pc2, f.pg2);
                     }
                 });
                 cur = nxt;
@@ -712,22 +800,32 @@ struct Engine {
 
     // Centering-corrector right-hand side (HPIPM compute_centering_correction: rm <- lam*t +
     // dlam_aff*dt_aff - sigma*mu, rebuild gt) followed by the backward SOLVE sweep on the
-    // existing factorisation.
+    // existing factorisation.  With Acl = A - B Kfb the vector recursion is
+    //     p_k = (gt_x - Kfb' gt_u) + Acl' (p_{k+1} + P_{k+1} rb_k),
+    // so everything except one 12-vector update per stage is computed for the whole chunk in
+    // parallel (before: P_{k+1} rb_k and gt_x - Kfb' gt_u; after: h_u = gt_u + B'(p_{k+1} + P_{k+1} rb_k)).
     MPC_PASS void corrector_bwd_pass(double sigma_mu)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = N;
-        constexpr int WLT = 48, WGR = 30;
-        const int CH = chunk_len(WLT + W3 + WGR + W4, W4);
+        constexpr int WLT = 48, WGR = 30, WV = 24;
+        const int CH = chunk_len(WLT + W3 + WGR + W4 + WV, W4);
+        typename Ex::template PerLane<D2> ab;   // lanes < 12: (a12, a22) of the lane's joint
+        ex.par([&](int lane) {
+            const int j = lane % 6;
+            D2 v; v.x = P.a12[j]; v.y = P.a22[j];
+            ab.at(lane) = v;
+        });
         int cur = 0;
         for (int k1 = Nl; k1 >= 0; k1 -= CH) {
             const int k0 = imax(k1 - CH + 1, 0), kh = imin(k1 + 1, Nl);
-            double *vlt = ex.pool();                        // rows k0..k1: QLAM | QT
+            double *vlt = ex.pool();                     // rows k0..k1: QLAM | QT
             double *v3 = vlt + (size_t)CH * WLT;         // rows k0..k1: G3 full
             double *vgr = v3 + (size_t)CH * W3;          // rows k0..k1: GT(18) | RB(12)
-            double *v4 = vgr + (size_t)CH * WGR;         // rows k0..kh: G4 full
+            double *vv = vgr + (size_t)CH * WGR;         // rows k0..k1: w = P_{k+1} rb (12) | g~ (12)
+            double *v4 = vv + (size_t)CH * WV;           // rows k0..kh: G4 full
             load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
             load_rect<W3, 0, W3>(v3, c.w.G3, k0, k1);
             load_rect<WGR, O_GT, W2>(vgr, c.w.G2, k0, k1);
@@ -755,8 +853,32 @@ struct Engine {
                     vgr[(size_t)s * WGR + j] = gt;
                 }
             });
+            // chunk-parallel: w_k = P_{k+1} rb_k and g~_k = gt_x - Kfb' gt_u
+            ex.par([&](int lane) {
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * 24; e += WAVE) {
+                    const int s = e / 24, i = e - s * 24, k = k0 + s;
+                    const double *gt = vgr + (size_t)s * WGR, *rbv = gt + 18;
+                    const double *fac = v4 + (size_t)s * W4;
+                    double v = 0.0;
+                    if (k < Nl) {
+                        if (i < 12) {
+                            const double *Mn = fac + W4 + O_PM + i * 12;
+#pragma unroll
+                            for (int j = 0; j < NX; j++) v += Mn[j] * rbv[j];
+                        } else {
+                            const int j = i - 12;
+                            v = gt[6 + j];
+#pragma unroll
+                            for (int m = 0; m < 6; m++) v -= fac[O_K + m * 12 + j] * gt[m];
+                        }
+                    }
+                    vv[(size_t)s * WV + i] = v;
+                }
+            });
             for (int k = k1; k >= k0; k--) {
-                const double *gt = vgr + (size_t)(k - k0) * WGR, *rbv = gt + 18;
+                const double *gt = vgr + (size_t)(k - k0) * WGR;
+                const double *wv = vv + (size_t)(k - k0) * WV;
                 double *fac = v4 + (size_t)(k - k0) * W4;
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
@@ -765,39 +887,41 @@ struct Engine {
                     });
                     continue;
                 }
-                const double *Mn = fac + W4 + O_PM;  // P_{k+1}
                 ex.par([&](int lane) {
                     if (lane < NX) {
-                        double s = sm.pv[cur][lane];
+                        const int j = lane;
+                        double mt[12];
 #pragma unroll
-                        for (int j = 0; j < NX; j++) s += Mn[lane * 12 + j] * rbv[j];
-                        sm.mt[lane] = s;
-                    }
-                });
-                ex.par([&](int lane) {
-                    double hu[6];
+                        for (int i = 0; i < NX; i++) mt[i] = sm.pv[cur][i] + wv[i];
+                        double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
-                    if (lane < NX) {
-                        double hx = gt[6 + lane];
-                        if (lane < 6) hx += sm.mt[lane];
-                        else hx += P.a12[lane - 6] * sm.mt[lane - 6] + P.a22[lane - 6] * sm.mt[lane];
-                        double pj = hx;
+                        for (int i = 0; i < 6; i++) acc += fac[O_K + i * 12 + j] * (P.b1[i] * mt[i] + P.b2[i] * mt[6 + i]);
+                        double own = mt[0], oq = mt[0];
 #pragma unroll
-                        for (int m = 0; m < 6; m++) pj -= fac[O_K + m * 12 + lane] * hu[m];
-                        sm.pv[nxt][lane] = pj;
-                        fac[O_PV + lane] = pj;
-                    }
-                    if (lane >= 32 && lane < 38) {  // a different lane set than the readers of fac[O_K..]
-                        const int jj = lane - 32;
-                        double v = hu[0];
+                        for (int i = 1; i < NX; i++) own = j == i ? mt[i] : own;
 #pragma unroll
-                        for (int j = 1; j < 6; j++) v = jj == j ? hu[j] : v;
-                        fac[O_HU + jj] = v;
+                        for (int i = 1; i < 6; i++) oq = (j - 6) == i ? mt[i] : oq;
+                        const D2 c2 = ab.at(lane);
+                        const double at = j < 6 ? own : c2.x * oq + c2.y * own;
+                        const double pj = wv[12 + j] + (at - acc);
+                        sm.pv[nxt][j] = pj;
+                        fac[O_PV + j] = pj;
                     }
                 });
                 cur = nxt;
             }
+            // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k)
+            ex.par([&](int lane) {
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * 6; e += WAVE) {
+                    const int s = e / 6, i = e - s * 6, k = k0 + s;
+                    if (k >= Nl) continue;
+                    const double *gt = vgr + (size_t)s * WGR, *wv = vv + (size_t)s * WV;
+                    double *fac = v4 + (size_t)s * W4;
+                    const double *pn = fac + W4 + O_PV;
+                    fac[O_HU + i] = gt[i] + P.b1[i] * (pn[i] + wv[i]) + P.b2[i] * (pn[6 + i] + wv[6 + i]);
+                }
+            });
             store_rect<24, O_RM, W3>(v3 + O_RM, c.w.G3, k0, k1, W3);
             store_rect<18, O_HU, W4>(v4 + O_HU, c.w.G4, k0, k1, W4);
         }
@@ -806,70 +930,107 @@ struct Engine {
 
     // Forward sweep: du = -Kfb dx - Rinv h_u ; dx+ = A dx + B du + rb ; dpi = P dx+ + p, then
     // dt, dlam from the primal step (HPIPM compute_lam_t), the largest feasible step and the
-    // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.
+    // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.  Only the state recursion
+    // dx_{k+1} = A dx_k - B (Kfb dx_k + Rinv h_u) + rb_k is sequential (one phase per stage);
+    // Rinv h_u before and du_k, dpi_{k-1} = P_k dx_k + p_k after it are chunk-parallel.
     MPC_PASS double forward_step_pass(double *S)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = N;
-        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78;
-        const int CH = chunk_len(W4 + WRB + WLT + WR + WO, 0);
+        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 6;
+        const int CH = chunk_len(W4 + WRB + WLT + WR + WO + WH, 0);
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
+        typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
         ex.par([&](int lane) {
+            const int j = lane % 6;
+            D2 v; v.x = P.a12[j]; v.y = P.a22[j];
+            ab.at(lane) = v;
+            D2 u; u.x = P.b1[j]; u.y = P.b2[j];
+            bb.at(lane) = u;
             if (lane < NX) sm.dx[0][lane] = 0.0;  // dx_0 = 0: x_0 is pinned by the init pass
         });
         int cur = 0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl);
-            double *v4 = ex.pool();                      // rows k0..k1, G4
+            double *v4 = ex.pool();                   // rows k0..k1, G4
             double *vrb = v4 + (size_t)CH * W4;       // RB
             double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
             double *vr = vlt + (size_t)CH * WLT;      // RD | RM
             double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
+            double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6)
             load_rect<W4, 0, W4>(v4, c.w.G4, k0, k1);
             load_rect<WRB, O_RB, W2>(vrb, c.w.G2, k0, k1);
             load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
             load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
+            ex.par([&](int lane) {
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * 6; e += WAVE) {
+                    const int s = e / 6, i = e - s * 6;
+                    const double *fac = v4 + (size_t)s * W4;
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) v += fac[O_RI + i * 6 + m] * fac[O_HU + m];
+                    vh[(size_t)s * WH + i] = v;
+                }
+            });
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * W4;
                 double *o = vo + (size_t)(k - k0) * WO;
-                // W0: lanes 0..5 -> du_k ; lanes 6..17 -> dpi_{k-1} = P_k dx_k + p_k ; lanes 18..29 log dx_k
-                ex.par([&](int lane) {
-                    if (lane < 18) {
-                        const bool isu = lane < 6;
-                        double s = 0.0;
-                        if ((isu && k < Nl) || (!isu && k >= 1)) {
-                            const double *row = isu ? fac + O_K + lane * 12 : fac + O_PM + (lane - 6) * 12;
-#pragma unroll
-                            for (int j = 0; j < NX; j++) s += row[j] * sm.dx[cur][j];
-                            if (isu) {
-#pragma unroll
-                                for (int m = 0; m < 6; m++) s += fac[O_RI + lane * 6 + m] * fac[O_HU + m];
-                                s = -s;
-                            } else {
-                                s += fac[O_PV + (lane - 6)];
-                            }
-                        }
-                        if (isu) { sm.du[lane] = s; o[lane] = s; }   // stage N has no input: 0
-                        else o[18 + (lane - 6)] = s;                 // DPI slot of stage k holds dpi_{k-1}
-                    } else if (lane < 30) {
-                        o[6 + (lane - 18)] = sm.dx[cur][lane - 18];
-                    }
-                });
-                if (k == Nl) break;
-                // W1: dx_{k+1}
                 ex.par([&](int lane) {
                     if (lane < NX) {
-                        double v;
-                        if (lane < 6) v = sm.dx[cur][lane] + P.a12[lane] * sm.dx[cur][6 + lane] + P.b1[lane] * sm.du[lane];
-                        else v = P.a22[lane - 6] * sm.dx[cur][lane] + P.b2[lane - 6] * sm.du[lane - 6];
-                        sm.dx[nxt][lane] = v + vrb[(size_t)(k - k0) * WRB + lane];
+                        const int i = lane < 6 ? lane : lane - 6;
+                        double dxv[12];
+#pragma unroll
+                        for (int j = 0; j < NX; j++) dxv[j] = sm.dx[cur][j];
+                        double own = dxv[0], ov = dxv[6];
+#pragma unroll
+                        for (int j = 1; j < NX; j++) own = lane == j ? dxv[j] : own;
+#pragma unroll
+                        for (int j = 1; j < 6; j++) ov = i == j ? dxv[6 + j] : ov;
+                        o[6 + lane] = own;   // dx_k
+                        if (k < Nl) {
+                            double s = vh[(size_t)(k - k0) * WH + i];
+#pragma unroll
+                            for (int j = 0; j < NX; j++) s += fac[O_K + i * 12 + j] * dxv[j];
+                            const double du = -s;
+                            const D2 a = ab.at(lane), b = bb.at(lane);
+                            const double v = lane < 6 ? own + a.x * ov + b.x * du : a.y * own + b.y * du;
+                            sm.dx[nxt][lane] = v + vrb[(size_t)(k - k0) * WRB + lane];
+                        }
                     }
                 });
-                cur = nxt;
+                if (k < Nl) cur = nxt;
             }
+            ex.par([&](int lane) {
+                const int rows = k1 - k0 + 1;
+                for (int e = lane; e < rows * 18; e += WAVE) {
+                    const int s = e / 18, ci = e - s * 18, k = k0 + s;
+                    const double *fac = v4 + (size_t)s * W4;
+                    double *o = vo + (size_t)s * WO;
+                    const double *dxk = o + 6;
+                    double v = 0.0;
+                    if (ci < 6) {
+                        if (k < Nl) {
+                            v = vh[(size_t)s * WH + ci];
+#pragma unroll
+                            for (int j = 0; j < NX; j++) v += fac[O_K + ci * 12 + j] * dxk[j];
+                            v = -v;
+                        }
+                        o[ci] = v;                      // du_k (stage N has no input: 0)
+                    } else {
+                        const int j = ci - 6;
+                        if (k >= 1) {
+                            v = fac[O_PV + j];
+#pragma unroll
+                            for (int i = 0; i < NX; i++) v += fac[O_PM + j * 12 + i] * dxk[i];
+                        }
+                        o[18 + j] = v;                  // DPI slot of stage k holds dpi_{k-1}
+                    }
+                }
+            });
             ex.par([&](int lane) {
                 double al = 1.0, a0 = 0, a1 = 0, a2 = 0;
                 const int rows = k1 - k0 + 1;
