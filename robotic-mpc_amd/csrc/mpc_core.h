@@ -18,6 +18,12 @@
 // coupling is the rank-5 task term 50*dt*G'G.  The 6x6 R~ is factorised redundantly by all
 // lanes (LDL'), the 18 right-hand sides (12 columns of S~, 6 of I) are solved one per lane.
 //
+// Lanes: a simulation is owned by NT = 64*NW lanes (NW wavefronts of one workgroup).  `ex.par`
+// phases run on all NT lanes and end with a workgroup barrier -- the chunk I/O and every
+// chunk-parallel phase; `ex.seq` phases run on wavefront 0 only (the stage-by-stage recursions,
+// whose phases are separated by a wave-local fence, no s_barrier); `ex.join()` is the barrier
+// that hands wave 0's results back to everybody.
+//
 // Memory: every pass streams CHUNKS of consecutive stage records HBM -> LDS -> HBM
 // (mpc_layout.h).  One IPM iteration is five passes: factorisation sweep, forward sweep +
 // step lengths, corrector + backward solve, forward sweep + step lengths, update + residuals.
@@ -100,15 +106,16 @@ MPC_HD void load_constants(Ex &ex, const InstParams *P, const Robot *rb)
     ex.par([&](int lane) {
         const double *ps = reinterpret_cast<const double *>(P);
         double *pd = reinterpret_cast<double *>(&sm.P);
-        for (int e = lane; e < (int)(sizeof(InstParams) / sizeof(double)); e += WAVE) pd[e] = ps[e];
+        for (int e = lane; e < (int)(sizeof(InstParams) / sizeof(double)); e += Ex::NT) pd[e] = ps[e];
         const double *rs = reinterpret_cast<const double *>(rb);
         double *rd = reinterpret_cast<double *>(&sm.rb);
-        for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) rd[e] = rs[e];
+        for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += Ex::NT) rd[e] = rs[e];
     });
 }
 
 template <class Ex>
 struct Engine {
+    static constexpr int NT = Ex::NT;  // lanes per simulation
     Ex &ex;
     Ctx c;
     int N;
@@ -141,9 +148,9 @@ struct Engine {
             // Sixteen individually named 16-byte registers per lane: all loads of a batch are issued
             // back to back and retired with counted vmcnt waits.  (A local array here lands in scratch
             // memory in the full kernel and serialises every load on `s_waitcnt vmcnt(0)`.)
-            for (int base = 0; base < tot; base += WAVE * 16) {
+            for (int base = 0; base < tot; base += NT * 16) {
 #define MPC_LD(u)                                                  \
-    const int e##u = imin(base + u * WAVE + lane, tot - 1);         \
+    const int e##u = imin(base + u * NT + lane, tot - 1);         \
     const int s##u = e##u / W2h;                                   \
     const D2 r##u = gb[(size_t)s##u * (LDG / 2) + (e##u - s##u * W2h)];
 #define MPC_ST(u) lb[e##u] = r##u;
@@ -166,9 +173,9 @@ struct Engine {
         const D2 *lb = reinterpret_cast<const D2 *>(l);
         PROF_T0(t0);
         ex.par([&](int lane) {
-            for (int base = 0; base < tot; base += WAVE * 16) {
+            for (int base = 0; base < tot; base += NT * 16) {
 #define MPC_LD(u)                                          \
-    const int e##u = imin(base + u * WAVE + lane, tot - 1); \
+    const int e##u = imin(base + u * NT + lane, tot - 1); \
     const D2 r##u = lb[e##u];
 #define MPC_ST(u)                      \
     {                                  \
@@ -218,7 +225,7 @@ struct Engine {
                     const int rows = hi - lo + 1;
                     // chunks run in increasing k: the lower halo row was already updated (and stored) by
                     // the previous chunk, the upper one has not been touched yet
-                    for (int e = lane; e < rows * NW; e += WAVE) {
+                    for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW;
                         if (lo + s < k0) continue;
                         double *r1 = v1 + (size_t)s * W1;
@@ -226,7 +233,7 @@ struct Engine {
                         else if (lo + s < Nl) r1[O_U + ci - 12] += alpha * r1[O_QW + ci - 12];
                     }
                     if (sqp_mult) {
-                        for (int e = lane; e < rows * 60; e += WAVE) {
+                        for (int e = lane; e < rows * 60; e += NT) {
                             const int s = e / 60, ci = e - s * 60;
                             if (lo + s < k0) continue;
                             const double *r1 = v1 + (size_t)s * W1;
@@ -239,7 +246,7 @@ struct Engine {
             }
             ex.par([&](int lane) {
                 double csum = 0.0;
-                for (int k = k0 + lane; k <= k1; k += WAVE) {
+                for (int k = k0 + lane; k <= k1; k += NT) {
                     double *rec = v2 + (size_t)(k - k0) * W2;
                     if (k < Nl) {
                         const double *r1 = v1 + (size_t)(k - lo) * W1, *rn = r1 + W1;
@@ -270,14 +277,14 @@ struct Engine {
                         for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
                     }
                 }
-                sm.red[0][lane] = csum;
+                sm.red[4][lane] = csum;
             });
-            cost += ex.reduce_sum(sm.red[0]);
+            cost += ex.reduce_sum(sm.red[4]);
             if (res4) {
                 ex.par([&](int lane) {
                     double a_s = 0, a_e = 0, a_i = 0, a_c = 0;
                     const int rows = k1 - k0 + 1;
-                    for (int e = lane; e < rows * NW; e += WAVE) {
+                    for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW, k = k0 + s;
                         const double *pi_k = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NPI : v1 + (size_t)(k - lo) * W1 + O_QPI;
                         const double *pi_m = sqp_mult ? v5 + (size_t)(imax(k - 1, lo) - lo) * 60 + O_NPI
@@ -333,9 +340,9 @@ struct Engine {
         const int ldl2 = ldl / 2;
         PROF_T0(t0);
         ex.par([&](int lane) {
-            for (int base = 0; base < tot; base += WAVE * 16) {
+            for (int base = 0; base < tot; base += NT * 16) {
 #define MPC_LD(u)                                          \
-    const int e##u = imin(base + u * WAVE + lane, tot - 1); \
+    const int e##u = imin(base + u * NT + lane, tot - 1); \
     const int s##u = e##u / W2h, c##u = e##u - s##u * W2h;  \
     const D2 r##u = lb[(size_t)s##u * ldl2 + c##u];
 #define MPC_ST(u) gb[(size_t)s##u * (LDG / 2) + c##u] = r##u;
@@ -419,16 +426,16 @@ struct Engine {
                 double ncl = 0.0;
                 if (mode == 1) {
                     // (lower halo row: already updated and stored by the previous chunk)
-                    for (int e = lane; e < rows * NW; e += WAVE) {
+                    for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW;
                         if (lo + s >= k0) v1[(size_t)s * W1 + O_QW + ci] += a * v3d[(size_t)s * W3D + ci];
                     }
-                    for (int e = lane; e < (rows - 1) * NX; e += WAVE) {  // pi_k += a * dpi stored at stage k+1
+                    for (int e = lane; e < (rows - 1) * NX; e += NT) {  // pi_k += a * dpi stored at stage k+1
                         const int s = e / NX, i = e - s * NX;
                         if (lo + s >= k0 && lo + s < Nl) v1[(size_t)s * W1 + O_QPI + i] += a * v3d[(size_t)(s + 1) * W3D + 18 + i];
                     }
                 }
-                for (int e = lane; e < rows * NB; e += WAVE) {
+                for (int e = lane; e < rows * NB; e += NT) {
                     const int s = e / NB, j = e - s * NB, k = lo + s;
                     if (k < k0 || k > k1) continue;  // multipliers are only needed on own rows
                     const bool hc = has_comp(Nl, k, j);
@@ -456,7 +463,7 @@ struct Engine {
             // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NTASK; e += WAVE) {
+                for (int e = lane; e < rows * NTASK; e += NT) {
                     const int s = e / NTASK, i = e - s * NTASK, k = k0 + s;
                     double *r2 = v2 + (size_t)s * W2_LIN;
                     if (k >= Nl) continue;
@@ -475,7 +482,7 @@ struct Engine {
             ex.par([&](int lane) {
                 double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NW; e += WAVE) {
+                for (int e = lane; e < rows * NW; e += NT) {
                     const int s = e / NW, ci = e - s * NW, k = k0 + s;
                     const double *r1 = v1 + (size_t)(k - lo) * W1;
                     const double *r2 = v2 + (size_t)s * W2_LIN;
@@ -517,7 +524,7 @@ struct Engine {
                     og[12 + ci] = gt;
                     a_g = fmax(a_g, fabs(rg));
                 }
-                for (int e = lane; e < rows * NX; e += WAVE) {
+                for (int e = lane; e < rows * NX; e += NT) {
                     const int s = e / NX, i = e - s * NX, k = k0 + s;
                     double v = 0.0;
                     if (k < Nl) {
@@ -637,7 +644,7 @@ struct Engine {
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12)
         const int CH = chunk_len(WR + W4, 0);
         typename Ex::template PerLane<FactLane> fl;
-        ex.par([&](int lane) {
+        ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
             s_item(P, lane, f.s1);
             f.x2_dst = -1; f.x2_gam = -1; f.x2_mirror = -1;
@@ -670,14 +677,14 @@ struct Engine {
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
                     // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x
-                    ex.par([&](int lane) {
+                    ex.seq([&](int lane) {
                         for (int e = lane; e < 144; e += WAVE) { sm.M[cur][e] = 0.0; fac[O_PM + e] = 0.0; }
                         if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
                     });
                     continue;
                 }
                 // ---- F0: S~ (72 entries), R~ (21 lower entries), m~ = p_{k+1} + P_{k+1} rb_k (12)
-                ex.par([&](int lane) {
+                ex.seq([&](int lane) {
                     const double *M = sm.M[cur];
                     const FactLane &f = fl.at(lane);
                     sm.St[lane] = eval_item(f.s1, M);
@@ -695,7 +702,7 @@ struct Engine {
                     }
                 });
                 // ---- F1: LDL' of R~ (redundant), one right-hand side per lane; vector part
-                ex.par([&](int lane) {
+                ex.seq([&](int lane) {
                     double hu[6];
 #pragma unroll
                     for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
@@ -754,7 +761,7 @@ struct Engine {
                     }
                 });
                 // ---- F2: p_k, and P_k = H_xx + Gamma_q + A'MA - S~' Kfb   (78 unique entries)
-                ex.par([&](int lane) {
+                ex.seq([&](int lane) {
                     const double *M = sm.M[cur];
                     const double *gq = ric, *gv = ric + 30;
                     const FactLane &f = fl.at(lane);
@@ -793,6 +800,7 @@ struct Engine {
                 });
                 cur = nxt;
             }
+            ex.join();
             store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
         }
         PROF_ADD(PF_FACT, t0);
@@ -813,7 +821,7 @@ struct Engine {
         constexpr int WLT = 48, WGR = 30, WV = 24;
         const int CH = chunk_len(WLT + W3 + WGR + W4 + WV, W4);
         typename Ex::template PerLane<D2> ab;   // lanes < 12: (a12, a22) of the lane's joint
-        ex.par([&](int lane) {
+        ex.seq([&](int lane) {
             const int j = lane % 6;
             D2 v; v.x = P.a12[j]; v.y = P.a22[j];
             ab.at(lane) = v;
@@ -832,7 +840,7 @@ struct Engine {
             load_rect<W4, 0, W4>(v4, c.w.G4, k0, kh);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NB; e += WAVE) {
+                for (int e = lane; e < rows * NB; e += NT) {
                     const int s = e / NB, j = e - s * NB, k = k0 + s;
                     if (!has_comp(Nl, k, j)) continue;
                     const double *lt = vlt + (size_t)s * WLT;
@@ -856,7 +864,7 @@ struct Engine {
             // chunk-parallel: w_k = P_{k+1} rb_k and g~_k = gt_x - Kfb' gt_u
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 24; e += WAVE) {
+                for (int e = lane; e < rows * 24; e += NT) {
                     const int s = e / 24, i = e - s * 24, k = k0 + s;
                     const double *gt = vgr + (size_t)s * WGR, *rbv = gt + 18;
                     const double *fac = v4 + (size_t)s * W4;
@@ -882,12 +890,12 @@ struct Engine {
                 double *fac = v4 + (size_t)(k - k0) * W4;
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
-                    ex.par([&](int lane) {
+                    ex.seq([&](int lane) {
                         if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
                     });
                     continue;
                 }
-                ex.par([&](int lane) {
+                ex.seq([&](int lane) {
                     if (lane < NX) {
                         const int j = lane;
                         double mt[12];
@@ -910,10 +918,11 @@ struct Engine {
                 });
                 cur = nxt;
             }
+            ex.join();
             // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k)
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 6; e += WAVE) {
+                for (int e = lane; e < rows * 6; e += NT) {
                     const int s = e / 6, i = e - s * 6, k = k0 + s;
                     if (k >= Nl) continue;
                     const double *gt = vgr + (size_t)s * WGR, *wv = vv + (size_t)s * WV;
@@ -943,7 +952,7 @@ struct Engine {
         const int CH = chunk_len(W4 + WRB + WLT + WR + WO + WH, 0);
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
         typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
-        ex.par([&](int lane) {
+        ex.seq([&](int lane) {
             const int j = lane % 6;
             D2 v; v.x = P.a12[j]; v.y = P.a22[j];
             ab.at(lane) = v;
@@ -966,7 +975,7 @@ struct Engine {
             load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 6; e += WAVE) {
+                for (int e = lane; e < rows * 6; e += NT) {
                     const int s = e / 6, i = e - s * 6;
                     const double *fac = v4 + (size_t)s * W4;
                     double v = 0.0;
@@ -979,7 +988,7 @@ struct Engine {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * W4;
                 double *o = vo + (size_t)(k - k0) * WO;
-                ex.par([&](int lane) {
+                ex.seq([&](int lane) {
                     if (lane < NX) {
                         const int i = lane < 6 ? lane : lane - 6;
                         double dxv[12];
@@ -1004,9 +1013,10 @@ struct Engine {
                 });
                 if (k < Nl) cur = nxt;
             }
+            ex.join();
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 18; e += WAVE) {
+                for (int e = lane; e < rows * 18; e += NT) {
                     const int s = e / 18, ci = e - s * 18, k = k0 + s;
                     const double *fac = v4 + (size_t)s * W4;
                     double *o = vo + (size_t)s * WO;
@@ -1034,7 +1044,7 @@ struct Engine {
             ex.par([&](int lane) {
                 double al = 1.0, a0 = 0, a1 = 0, a2 = 0;
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NB; e += WAVE) {
+                for (int e = lane; e < rows * NB; e += NT) {
                     const int s = e / NB, j = e - s * NB, k = k0 + s;
                     const bool hc = has_comp(Nl, k, j);
                     const double *lt = vlt + (size_t)s * WLT, *r = vr + (size_t)s * WR;
@@ -1135,7 +1145,7 @@ struct Engine {
             if (update_weights) {
                 ex.par([&](int lane) {
                     const int rows = k1 - k0 + 1;
-                    for (int e = lane; e < rows * WMW; e += WAVE) {
+                    for (int e = lane; e < rows * WMW; e += NT) {
                         const int s = e / WMW, i = e - s * WMW;
                         const double *r1 = v1 + (size_t)s * W1;
                         const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
@@ -1147,7 +1157,7 @@ struct Engine {
             }
             ex.par([&](int lane) {
                 double acc = 0.0;
-                for (int k = k0 + lane; k <= k1; k += WAVE) {
+                for (int k = k0 + lane; k <= k1; k += NT) {
                     const double *r1 = v1 + (size_t)(k - k0) * W1, *rn = r1 + W1;
                     const double *mw = vm + (size_t)(k - k0) * WMW;
                     double xx[12], uu[6], rec[8];  // task_lin<false> only writes rec[O_R..O_R+4]
@@ -1297,10 +1307,10 @@ struct Engine {
             // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0 (SURVEY A.7 iv)
             const size_t tot = (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES;
             ex.par([&](int lane) {
-                for (size_t e = lane; e < tot; e += WAVE) w.G1[e] = 0.0;  // G1 is the workspace base
+                for (size_t e = lane; e < tot; e += NT) w.G1[e] = 0.0;  // G1 is the workspace base
             });
             ex.par([&](int lane) {
-                for (int e = lane; e < (N + 1) * NX; e += WAVE) {
+                for (int e = lane; e < (N + 1) * NX; e += NT) {
                     const int k = e / NX, i = e - k * NX;
                     w.G1[(size_t)k * W1 + O_X + i] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
                 }

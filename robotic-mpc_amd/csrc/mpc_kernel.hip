@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -29,58 +30,97 @@ extern __shared__ __attribute__((aligned(16))) double g_pool[];
 
 // Stateless on purpose: inside a non-inlined pass the executor is reached through `this`, and a
 // data member (e.g. a cached lane id) would be re-loaded from the stack at every phase.
+// NWV wavefronts (one workgroup) cooperate on one simulation.
+template <int NWV>
 struct DevExec {
+    static constexpr int NT = WAVE * NWV;
     __device__ __forceinline__ static int lane_id() { return (int)threadIdx.x; }
     __device__ __forceinline__ Smem &smem() const { return g_sm; }
     __device__ __forceinline__ double *pool() const { return g_pool; }
-    // per-lane registers that live across phases (prefetched stage records)
+    // per-lane registers that live across phases
     template <class T>
     struct PerLane {
         T v;
         __device__ __forceinline__ T &at(int) { return v; }
     };
+    __device__ __forceinline__ static void wave_fence()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // phase on all NT lanes, then a workgroup barrier (a wave-local fence when one wave owns the sim)
     template <class F>
     __device__ __forceinline__ void par(F &&f)
     {
         f(lane_id());
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (NWV == 1) wave_fence();
+        else __syncthreads();
     }
+    // phase on wavefront 0 only; consecutive seq phases need no s_barrier (one wave, in-order LDS)
+    template <class F>
+    __device__ __forceinline__ void seq(F &&f)
+    {
+        if (NWV == 1 || threadIdx.x < WAVE) {
+            f(lane_id());
+            wave_fence();
+        }
+    }
+    __device__ __forceinline__ void join()
+    {
+        if (NWV > 1) __syncthreads();
+    }
+    // every wave reduces all NWV segments itself: same order, same bits, no extra barrier
     __device__ __forceinline__ double reduce_sum(const double *r)
     {
-        double v = r[lane_id()];
+        double tot = 0.0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
+        for (int w = 0; w < NWV; w++) {
+            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            tot += v;
+        }
+        return tot;
     }
     __device__ __forceinline__ double reduce_max(const double *r)
     {
-        double v = r[lane_id()];
+        double tot = r[lane_id() & (WAVE - 1)];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-        return v;
+        for (int w = 0; w < NWV; w++) {
+            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+            tot = fmax(tot, v);
+        }
+        return tot;
     }
     __device__ __forceinline__ double reduce_min(const double *r)
     {
-        double v = r[lane_id()];
+        double tot = r[lane_id() & (WAVE - 1)];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-        return v;
+        for (int w = 0; w < NWV; w++) {
+            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+            tot = fmin(tot, v);
+        }
+        return tot;
     }
     // constant 100 MHz counter (s_memrealtime)
     __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
 };
 
-__global__ __launch_bounds__(WAVE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+template <int NWV>
+__global__ __launch_bounds__(WAVE *NWV) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
                                                            double *ws_base, size_t ws_stride, Outputs out, int step0,
                                                            int step1, int pool_doubles)
 {
     const int inst = blockIdx.x;
     if (inst >= pb.batch) return;
-    DevExec ex;
+    DevExec<NWV> ex;
     load_constants(ex, params + inst, &rb);
     Ctx c{&pb, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), pool_doubles, pb.N};
-    Engine<DevExec> eng(ex, c);
+    Engine<DevExec<NWV>> eng(ex, c);
     eng.rollout(out, inst, step0, step1);
 }
 
@@ -99,6 +139,7 @@ struct mpcb_handle {
     size_t ws_stride = 0;
     int pool_doubles = POOL_DEFAULT_DOUBLES;
     int num_cus = 256;
+    int waves_per_sim = 4;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -234,8 +275,15 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         if (bytes > POOL_DEFAULT_DOUBLES * 8) bytes = POOL_DEFAULT_DOUBLES * 8;
         if (bytes < POOL_MIN_DOUBLES * 8) bytes = POOL_MIN_DOUBLES * 8;
         h->pool_doubles = (bytes / 16) * 2;
-        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      h->pool_doubles * (int)sizeof(double)));
+        // wavefronts per simulation: the four SIMDs of a CU are otherwise idle at one simulation per CU
+        const char *env = getenv("MPCB_WAVES_PER_SIM");
+        int nw = wpc <= 1 ? 4 : (wpc <= 2 ? 2 : 1);
+        if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4)) nw = atoi(env);
+        h->waves_per_sim = nw;
+        const int lds_bytes = h->pool_doubles * (int)sizeof(double);
+        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
     h->ready = true;
     h->next_step = 0;
@@ -259,8 +307,17 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     Outputs out;
     std::memcpy(&out, o, sizeof out);
     HIPCHK(h, hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(mpc_rollout_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), (size_t)h->pool_doubles * sizeof(double), s,
-                       h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out, step0, step1, h->pool_doubles);
+    const size_t lds = (size_t)h->pool_doubles * sizeof(double);
+    const dim3 grid((unsigned)h->pb.batch);
+    if (h->waves_per_sim == 4)
+        hipLaunchKernelGGL(mpc_rollout_kernel<4>, grid, dim3(WAVE * 4), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
+                           h->ws_stride, out, step0, step1, h->pool_doubles);
+    else if (h->waves_per_sim == 2)
+        hipLaunchKernelGGL(mpc_rollout_kernel<2>, grid, dim3(WAVE * 2), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
+                           h->ws_stride, out, step0, step1, h->pool_doubles);
+    else
+        hipLaunchKernelGGL(mpc_rollout_kernel<1>, grid, dim3(WAVE), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
+                           h->ws_stride, out, step0, step1, h->pool_doubles);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, s));
     h->last_stream = s;
@@ -290,7 +347,9 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
 {
     if (!h) return MPCB_EINVAL;
     hipFuncAttributes a;
-    HIPCHK(h, hipFuncGetAttributes(&a, (const void *)mpc_rollout_kernel));
+    HIPCHK(h, hipFuncGetAttributes(&a, h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
+                                       : h->waves_per_sim == 2 ? (const void *)mpc_rollout_kernel<2>
+                                                               : (const void *)mpc_rollout_kernel<1>));
     if (vgprs) *vgprs = a.numRegs;
     if (sgprs) *sgprs = 0;
     if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;

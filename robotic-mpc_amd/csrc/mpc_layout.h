@@ -27,6 +27,7 @@
 namespace mpcb {
 
 constexpr int WAVE = 64;
+constexpr int NT_MAX = 256;  // at most four wavefronts cooperate on one simulation
 constexpr int NQ = 6;   // joints
 constexpr int NX = 12;  // state  x = [q; qdot]              (prediction_model.py:46)
 constexpr int NU = 6;   // input  u = qdot_ref                (prediction_model.py:47)
@@ -154,7 +155,7 @@ struct Smem {
     double hx[12];      // h_x
     double dx[2][12];
     double du[6];
-    double red[8][WAVE];
+    double red[8][NT_MAX];
     double xhat[12];    // current plant state (feedback, simulator.py:206)
     double u0[6];
     double logv[40];

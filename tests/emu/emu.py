@@ -22,7 +22,7 @@ def build(force=False):
     return _LIB
 
 
-def run(cfgs, chain, step_chunk=0, pool_doubles=0):
+def run(cfgs, chain, step_chunk=0, pool_doubles=0, waves=1):
     """cfgs: list of resolved configs sharing one bucket. Returns dict of arrays [batch, ...]."""
     from robotic_mpc_amd import packing
 
@@ -47,6 +47,7 @@ def run(cfgs, chain, step_chunk=0, pool_doubles=0):
         args.append(o[k].ctypes.data_as(dp))
     args.append(C.c_int(step_chunk))
     args.append(C.c_int(pool_doubles))
+    args.append(C.c_int(waves))
     rc = lib.emu_run(*args)
     assert rc == 0
     return o

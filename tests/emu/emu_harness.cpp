@@ -16,35 +16,41 @@
 
 using namespace mpcb;
 
+template <int NWV>
 struct HostExec {
+    static constexpr int NT = WAVE * NWV;
     Smem *sm_;
     double *pool_;
     Smem &smem() const { return *sm_; }
     double *pool() const { return pool_; }
     template <class T>
     struct PerLane {
-        T v[WAVE];
+        T v[WAVE * NWV];
         T &at(int l) { return v[l]; }
     };
     template <class F>
     void par(F &&f)
     {
+        for (int l = 0; l < NT; l++) f(l);
+    }
+    template <class F>
+    void seq(F &&f)
+    {
         for (int l = 0; l < WAVE; l++) f(l);
     }
-    double reduce_sum(const double *r) { double s = 0; for (int l = 0; l < WAVE; l++) s += r[l]; return s; }
-    double reduce_max(const double *r) { double s = r[0]; for (int l = 1; l < WAVE; l++) s = fmax(s, r[l]); return s; }
-    double reduce_min(const double *r) { double s = r[0]; for (int l = 1; l < WAVE; l++) s = fmin(s, r[l]); return s; }
+    void join() {}
+    double reduce_sum(const double *r) { double s = 0; for (int l = 0; l < NT; l++) s += r[l]; return s; }
+    double reduce_max(const double *r) { double s = r[0]; for (int l = 1; l < NT; l++) s = fmax(s, r[l]); return s; }
+    double reduce_min(const double *r) { double s = r[0]; for (int l = 1; l < NT; l++) s = fmin(s, r[l]); return s; }
     double clock() { return 0.0; }
 };
 
-extern "C" int emu_run(const Problem *pb, const double *robot105, const double *params /* [batch][MPCB_NPARAM] */,
-                       double *z, double *u, double *ee_pose, double *ee_rpy, double *ee_vel, int *status,
-                       int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time,
-                       int step_chunk, int pool_doubles)
+template <int NWV>
+static int emu_run_t(const Problem *pb, const double *robot105, const double *params, Outputs out, int step_chunk,
+                     int pool_doubles)
 {
     Robot rb;
     std::memcpy(&rb, robot105, sizeof(Robot));
-    Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time};
     const size_t wsd = ws_doubles_per_instance(pb->N);
     std::vector<double> ws(wsd);
     for (int inst = 0; inst < pb->batch; inst++) {
@@ -54,15 +60,26 @@ extern "C" int emu_run(const Problem *pb, const double *robot105, const double *
         std::memset(&sm, 0, sizeof sm);
         if (pool_doubles <= 0) pool_doubles = POOL_DEFAULT_DOUBLES;
         std::vector<double> pool((size_t)pool_doubles + 64, 0.0);
-        HostExec ex{&sm, pool.data()};
+        HostExec<NWV> ex{&sm, pool.data()};
         if (step_chunk <= 0) step_chunk = pb->Nsim;
         for (int s0 = 0; s0 < pb->Nsim; s0 += step_chunk) {
             load_constants(ex, &P, &rb);
             Ctx c{pb, ws_carve(ws.data(), pb->N), pool_doubles, pb->N};
-            Engine<HostExec> eng(ex, c);
+            Engine<HostExec<NWV>> eng(ex, c);
             const int s1 = s0 + step_chunk < pb->Nsim ? s0 + step_chunk : pb->Nsim;
             eng.rollout(out, inst, s0, s1);
         }
     }
     return 0;
+}
+
+extern "C" int emu_run(const Problem *pb, const double *robot105, const double *params /* [batch][MPCB_NPARAM] */,
+                       double *z, double *u, double *ee_pose, double *ee_rpy, double *ee_vel, int *status,
+                       int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time,
+                       int step_chunk, int pool_doubles, int waves)
+{
+    Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time};
+    if (waves == 4) return emu_run_t<4>(pb, robot105, params, out, step_chunk, pool_doubles);
+    if (waves == 2) return emu_run_t<2>(pb, robot105, params, out, step_chunk, pool_doubles);
+    return emu_run_t<1>(pb, robot105, params, out, step_chunk, pool_doubles);
 }

@@ -25,16 +25,17 @@ def _cfg(**kw):
 
 # pool = LDS chunk pool in doubles: 2048 forces chunks of 3-7 stages (many chunk seams and halos),
 # 0 = the default 128 KiB pool (one or two chunks)
-@pytest.mark.parametrize("N,T,solver,chunk,pool", [
-    (20, 0.6, "SQP_RTI", 0, 0), (20, 0.3, "SQP", 0, 0), (1, 0.1, "SQP_RTI", 0, 0), (2, 0.1, "SQP", 0, 2048),
-    (65, 0.2, "SQP_RTI", 7, 0), (130, 0.05, "SQP_RTI", 0, 0), (23, 0.3, "SQP_RTI", 0, 2048), (11, 0.2, "SQP", 3, 2048),
-    (100, 0.05, "SQP_RTI", 0, 4096)])
-def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk, pool):
+# waves = wavefronts cooperating on one simulation (64 lanes each)
+@pytest.mark.parametrize("N,T,solver,chunk,pool,waves", [
+    (20, 0.6, "SQP_RTI", 0, 0, 1), (20, 0.3, "SQP", 0, 0, 4), (1, 0.1, "SQP_RTI", 0, 0, 4), (2, 0.1, "SQP", 0, 2048, 2),
+    (65, 0.2, "SQP_RTI", 7, 0, 4), (130, 0.05, "SQP_RTI", 0, 0, 4), (23, 0.3, "SQP_RTI", 0, 2048, 4),
+    (11, 0.2, "SQP", 3, 2048, 1), (100, 0.05, "SQP_RTI", 0, 4096, 2)])
+def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk, pool, waves):
     import emu
 
     cfg = _cfg(prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
     ref = orc.run(ur10_rb, orc.make_params(cfg))
-    out = emu.run([cfg], ur10, step_chunk=chunk, pool_doubles=pool)
+    out = emu.run([cfg], ur10, step_chunk=chunk, pool_doubles=pool, waves=waves)
     for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
         np.testing.assert_allclose(out[k][0], ref[k], atol=1e-11, rtol=0, err_msg=k)
     np.testing.assert_allclose(out["cost"][0], ref["cost"], atol=1e-10, rtol=1e-10)
@@ -53,7 +54,7 @@ def test_emulated_engine_active_bounds_and_batch(orc, ur10, ur10_rb):
         _cfg(prediction_horizon=15, simulation_time=0.3, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
              w_qddot=0.05, px_ref=0.5, vy_ref=-0.02, surface_coeffs=dict(a=-0.1, b=0.12, c=0.0, d=0.02, e=-0.01, f=0.05)),
     ]
-    out = emu.run(cfgs, ur10)
+    out = emu.run(cfgs, ur10, waves=4)
     for i, cfg in enumerate(cfgs):
         ref = orc.run(ur10_rb, orc.make_params(cfg))
         np.testing.assert_allclose(out["z"][i], ref["z"], atol=1e-9, rtol=0)
