@@ -44,7 +44,7 @@ constexpr double BOUND_INF = 1e29;
 #define PROF_T0(v)
 #define PROF_ADD(i, v)
 #endif
-enum { PF_NLP = 0, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_MERIT, PF_PLANT, PF_TOTAL, PF_COUNT_IPM, PF_IO };
+enum { PF_NLP = 0, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_MERIT, PF_PLANT, PF_TOTAL, PF_COUNT_IPM, PF_IO, PF_SEQ_FACT, PF_SEQ_BWD, PF_SEQ_FWD };
 
 // The LDS working set is reached through the executor (ex.smem(), ex.pool()) and never through a
 // stored pointer: inside a non-inlined pass a pointer loaded from `this` is a generic (flat)
@@ -670,6 +670,7 @@ struct Engine {
             double *vr = ex.pool();                // rows k0..k1, 78: GQ 0, GV 30, GAM 36, GT 48, RB 66
             double *vf = vr + (size_t)CH * WR;     // rows k0..k1, W4
             load_rect<WR, O_GQ, W2>(vr, c.w.G2, k0, k1);
+            PROF_T0(ts);
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - k0) * WR;
                 double *fac = vf + (size_t)(k - k0) * W4;
@@ -801,6 +802,7 @@ struct Engine {
                 cur = nxt;
             }
             ex.join();
+            PROF_ADD(PF_SEQ_FACT, ts);
             store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
         }
         PROF_ADD(PF_FACT, t0);
@@ -884,6 +886,7 @@ struct Engine {
                     vv[(size_t)s * WV + i] = v;
                 }
             });
+            PROF_T0(ts);
             for (int k = k1; k >= k0; k--) {
                 const double *gt = vgr + (size_t)(k - k0) * WGR;
                 const double *wv = vv + (size_t)(k - k0) * WV;
@@ -919,6 +922,7 @@ struct Engine {
                 cur = nxt;
             }
             ex.join();
+            PROF_ADD(PF_SEQ_BWD, ts);
             // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k)
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -984,6 +988,7 @@ struct Engine {
                     vh[(size_t)s * WH + i] = v;
                 }
             });
+            PROF_T0(ts);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * W4;
@@ -1014,6 +1019,7 @@ struct Engine {
                 if (k < Nl) cur = nxt;
             }
             ex.join();
+            PROF_ADD(PF_SEQ_FWD, ts);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 18; e += NT) {

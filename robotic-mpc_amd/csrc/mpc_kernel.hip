@@ -269,9 +269,13 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
     // LDS chunk pool: the whole 160 KiB of a CU is shared by the waves resident on it, so size the
     // pool for the number of simulations per CU this batch implies (1 for batch <= #CUs).
     {
-        const int wpc = (p->batch + h->num_cus - 1) / h->num_cus;
+        // More than a few resident simulations per CU only shrinks the chunks (more, smaller bursts);
+        // beyond that the grid simply queues.  MPCB_SIMS_PER_CU overrides the residency target.
+        int wpc = (p->batch + h->num_cus - 1) / h->num_cus;
+        if (wpc > 2) wpc = 2;
+        if (const char *e2 = getenv("MPCB_SIMS_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 8) wpc = v; }
         const int lds_total = 160 * 1024, fixed = (int)sizeof(Smem) + 1024;
-        int bytes = lds_total / (wpc < 1 ? 1 : (wpc > 8 ? 8 : wpc)) - fixed;
+        int bytes = lds_total / (wpc < 1 ? 1 : wpc) - fixed;
         if (bytes > POOL_DEFAULT_DOUBLES * 8) bytes = POOL_DEFAULT_DOUBLES * 8;
         if (bytes < POOL_MIN_DOUBLES * 8) bytes = POOL_MIN_DOUBLES * 8;
         h->pool_doubles = (bytes / 16) * 2;

@@ -1,0 +1,28 @@
+"""Throughput / robustness sweep of the engine over horizons, batch sizes and solver types."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from robotic_mpc_amd import engine, robots
+
+eng = engine.MpcBatchEngine(0)
+ch = robots.builtin_chain("ur10")
+print("kernel", eng.kernel_info(), flush=True)
+cases = [(256, 20, "SQP_RTI", 6.0), (256, 50, "SQP_RTI", 6.0), (256, 100, "SQP_RTI", 6.0), (256, 200, "SQP_RTI", 3.0),
+         (256, 300, "SQP_RTI", 2.0), (64, 100, "SQP_RTI", 6.0), (512, 100, "SQP_RTI", 6.0), (1024, 100, "SQP_RTI", 3.0),
+         (4096, 100, "SQP_RTI", 1.0), (256, 100, "SQP", 3.0), (512, 100, "SQP", 2.0)]
+if os.environ.get("SWEEP_B"):
+    bs = [int(v) for v in os.environ["SWEEP_B"].split(",")]
+    cases = [c for c in cases if c[0] in bs and c[2] == "SQP_RTI" and c[1] == 100]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if str(c[1]) in sys.argv[1:] or c[2] in sys.argv[1:]]
+for B, N, solver, T in cases:
+    cfgs = bench.workload_configs(B, N, T, seed=1, solver=solver)
+    t = time.time()
+    pb, bufs = eng.run_device(cfgs, ch)
+    ms = sum(eng.last_kernel_ms)
+    st = bufs["status"]
+    print(f"B={B:5d} N={N:3d} {solver:7s} Nsim={pb.Nsim:4d}: kernel {ms:8.1f} ms  {B*pb.Nsim/(ms*1e-3):10.0f} steps/s  "
+          f"qp_it/step {bufs['qp_iter'].double().mean().item():.2f} sqp_it {bufs['sqp_iter'].double().mean().item():.2f} "
+          f"fail {(st != 0).sum().item()} final cost max {bufs['cost'][:, -1].max().item():.2e}", flush=True)
