@@ -556,189 +556,127 @@ struct Engine {
     }
 
     // =========================================================================== Riccati passes
-    // A lane's work items in the factorisation sweep are the same for every stage, so the index
-    // decoding and the products of model constants are hoisted out of the stage loop into
-    // per-lane registers.  Item = sum_t coef[t] * M[off[t]] + cst.
-    struct Item4 {
-        double coef[4];
-        double cst;
-        int off[4];
-    };
+    // Factorisation sweep.  Lane l < 36 owns block position (a,b) = (l/6, l%6) of the 12x12
+    // cost-to-go M = [[Mqq Mqv],[Mvq Mvv]] -- its four entries live in the lane's registers for
+    // the whole sweep.  Because A and B have diagonal blocks, everything stage k-1 needs from
+    // M = P_k at position (a,b) -- R~(a,b), S~(a,b), S~(a,6+b) and the A'MA block -- is a
+    // combination of those four numbers, so M never travels through LDS.  Two phases per stage:
+    //   B : LDL' of R~ (redundant in all lanes, right-looking), Kfb columns / R~^-1 columns one per
+    //       lane; lanes 40..51: m~ = p_{k+1} + P_{k+1} rb_k
+    //   CA: P_k block = A'MA + H_xx + Gamma_q - S~' Kfb  (-> registers, LDS record), then at once
+    //       R~, S~ of stage k-1; lanes 40..51: h_u, p_k
     struct FactLane {
-        Item4 s1;        // S~ entry e = lane                         (every lane)
-        Item4 x2;        // lanes 0..7: S~ entry 64+lane ; lanes 8..28: R~ entry lane-8
-        int x2_dst;      // LDS destination of x2 (index into St, or into Rt with bit 30 set)
-        int x2_gam;      // Gamma_u index added to x2 (diagonal R~ entries), -1 otherwise
-        int x2_mirror;   // mirrored Rt destination, -1 otherwise
-        Item4 p1, p2;    // A'MA parts of P entries e = lane and (lanes 0..13) 64 + lane
-        int pi1, pj1, pi2, pj2;   // their (i, j), i >= j
-        double pc1, pc2; // constant parts of H_xx for them (dt*w*c^2 on the vv diagonal)
-        int pg1, pg2;    // Gamma_q index on the qq diagonal, -1 otherwise
+        double b1a, b2a, b1b, b2b, a12a, a22a, a12b, a22b;
+        double hu_c;     // dt (2 w_u + w_qddot c_a^2) on the diagonal of R~, 0 off it
+        double huv_c;    // dt w_qddot c_a^2 on the diagonals, 0 off them
+        double mqq, mqv, mvq, mvv;   // P_{k+1} block (a,b)
+        double qqq, qqv, qvq, qvv;   // A' P_{k+1} A block (a,b)
+        int a, b;
     };
 
-    MPC_HD static void s_item(const InstParams &P, int e, Item4 &it)
-    {
-        const int m = e / 12, cc = e - m * 12;
-        if (cc < 6) {
-            it.coef[0] = P.b1[m]; it.off[0] = m * 12 + cc;
-            it.coef[1] = P.b2[m]; it.off[1] = (6 + m) * 12 + cc;
-            it.coef[2] = 0.0; it.off[2] = 0;
-            it.coef[3] = 0.0; it.off[3] = 0;
-            it.cst = 0.0;
-        } else {
-            const int j = cc - 6;
-            it.coef[0] = P.b1[m] * P.a12[j]; it.off[0] = m * 12 + j;
-            it.coef[1] = P.b2[m] * P.a12[j]; it.off[1] = (6 + m) * 12 + j;
-            it.coef[2] = P.b1[m] * P.a22[j]; it.off[2] = m * 12 + 6 + j;
-            it.coef[3] = P.b2[m] * P.a22[j]; it.off[3] = (6 + m) * 12 + 6 + j;
-            it.cst = m == j ? -(P.dt * P.w_qddot * P.cq[j] * P.cq[j]) : 0.0;
-        }
-    }
-    MPC_HD static void r_item(const InstParams &P, int e, Item4 &it, int &i, int &j)
-    {
-        tri_index(e, i, j);
-        it.coef[0] = P.b1[i] * P.b1[j]; it.off[0] = i * 12 + j;
-        it.coef[1] = P.b2[i] * P.b1[j]; it.off[1] = (6 + i) * 12 + j;
-        it.coef[2] = P.b1[i] * P.b2[j]; it.off[2] = i * 12 + 6 + j;
-        it.coef[3] = P.b2[i] * P.b2[j]; it.off[3] = (6 + i) * 12 + 6 + j;
-        it.cst = i == j ? P.dt * (2.0 * P.w_u + P.w_qddot * P.cq[i] * P.cq[i]) : 0.0;
-    }
-    // A'MA part of P(i,j), i >= j
-    MPC_HD static void p_item(const InstParams &P, int e, Item4 &it, int &i, int &j, double &cst, int &gam)
-    {
-        tri_index(e, i, j);
-        cst = 0.0; gam = -1;
-#pragma unroll
-        for (int t = 0; t < 4; t++) { it.coef[t] = 0.0; it.off[t] = 0; }
-        it.cst = 0.0;
-        if (i < 6) {
-            it.coef[0] = 1.0; it.off[0] = i * 12 + j;
-            if (i == j) gam = 6 + i;
-        } else if (j < 6) {
-            const int a = i - 6, b = j;
-            it.coef[0] = P.a12[a]; it.off[0] = a * 12 + b;
-            it.coef[1] = P.a22[a]; it.off[1] = (6 + a) * 12 + b;
-        } else {
-            const int a = i - 6, b = j - 6;
-            it.coef[0] = P.a12[a] * P.a12[b]; it.off[0] = a * 12 + b;
-            it.coef[1] = P.a22[a] * P.a12[b]; it.off[1] = (6 + a) * 12 + b;
-            it.coef[2] = P.a12[a] * P.a22[b]; it.off[2] = a * 12 + 6 + b;
-            it.coef[3] = P.a22[a] * P.a22[b]; it.off[3] = (6 + a) * 12 + 6 + b;
-            if (a == b) cst = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
-        }
-    }
-    MPC_HD static double eval_item(const Item4 &it, const double *M)
-    {
-        return it.coef[0] * M[it.off[0]] + it.coef[1] * M[it.off[1]] + it.coef[2] * M[it.off[2]] +
-               it.coef[3] * M[it.off[3]] + it.cst;
-    }
-
-    // Factorisation sweep (backward over chunks): per stage rebuild (R~, S~, P) from Gamma and the
-    // Jacobians, Kfb = R~^-1 S~, R~^-1, P_k, and propagate the vector part (gt, rb) -> p_k, h_u.
     MPC_PASS void fact_pass()
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = N;
-        constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12)
-        const int CH = chunk_len(WR + W4, 0);
+        constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
+        const int CH = chunk_len(WR + W4, WR);
         typename Ex::template PerLane<FactLane> fl;
         ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
-            s_item(P, lane, f.s1);
-            f.x2_dst = -1; f.x2_gam = -1; f.x2_mirror = -1;
-            if (lane < 8) {
-                s_item(P, 64 + lane, f.x2);
-                f.x2_dst = 64 + lane;
-            } else if (lane < 29) {
-                int i, j;
-                r_item(P, lane - 8, f.x2, i, j);
-                f.x2_dst = (1 << 30) | (i * 6 + j);
-                f.x2_mirror = j * 6 + i;
-                f.x2_gam = i == j ? i : -1;
-            } else {
-                s_item(P, lane, f.x2);  // unused, keeps the registers defined
-            }
-            p_item(P, lane, f.p1, f.pi1, f.pj1, f.pc1, f.pg1);
-            p_item(P, lane < 14 ? 64 + lane : lane, f.p2, f.pi2, f.pj2, f.pc2, f.pg2);
+            const int a = lane < 36 ? lane / 6 : 0, b = lane < 36 ? lane % 6 : 0;
+            f.a = a; f.b = b;
+            f.b1a = P.b1[a]; f.b2a = P.b2[a]; f.b1b = P.b1[b]; f.b2b = P.b2[b];
+            f.a12a = P.a12[a]; f.a22a = P.a22[a]; f.a12b = P.a12[b]; f.a22b = P.a22[b];
+            const double c2 = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
+            f.hu_c = a == b ? P.dt * 2.0 * P.w_u + c2 : 0.0;
+            f.huv_c = a == b ? c2 : 0.0;
+            f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
+            f.qqq = f.qqv = f.qvq = f.qvv = 0.0;
         });
-        const double dtw5 = P.dt * P.w_task[4];
-        int cur = 0;
+        const double dw0 = P.dt * P.w_task[0], dw1 = P.dt * P.w_task[1], dw2 = P.dt * P.w_task[2], dw3 = P.dt * P.w_task[3],
+                     dw4 = P.dt * P.w_task[4];
+        // R~, S~ of stage `kd` from the lane's block of P_{kd+1}; also the A'MA block for stage kd
+        auto next_stage = [&](int lane, FactLane &f, const double *gam_kd, int sb) {
+            const double fq = f.b1a * f.mqq + f.b2a * f.mvq, fv = f.b1a * f.mqv + f.b2a * f.mvv;
+            double r = fq * f.b1b + fv * f.b2b + f.hu_c;
+            if (f.a == f.b) r += gam_kd[f.a];
+            sm.Rt[f.a * 6 + f.b] = r;
+            double *St = sm.St2[sb];
+            St[f.a * 12 + f.b] = fq;
+            St[f.a * 12 + 6 + f.b] = fq * f.a12b + fv * f.a22b - f.huv_c;
+            const double cq = f.a12a * f.mqq + f.a22a * f.mvq, cv = f.a12a * f.mqv + f.a22a * f.mvv;
+            f.qqq = f.mqq;
+            f.qqv = f.mqq * f.a12b + f.mqv * f.a22b;
+            f.qvq = cq;
+            f.qvv = cq * f.a12b + cv * f.a22b;
+            (void)lane;
+        };
+        int cur = 0, sb = 0;
         for (int k1 = Nl; k1 >= 0; k1 -= CH) {
-            const int k0 = imax(k1 - CH + 1, 0);
-            double *vr = ex.pool();                // rows k0..k1, 78: GQ 0, GV 30, GAM 36, GT 48, RB 66
-            double *vf = vr + (size_t)CH * WR;     // rows k0..k1, W4
-            load_rect<WR, O_GQ, W2>(vr, c.w.G2, k0, k1);
+            const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
+            double *vr = ex.pool();                      // rows kl..k1 (one halo row below: Gamma of stage k0-1)
+            double *vf = vr + (size_t)(CH + 1) * WR;     // rows k0..k1, W4
+            load_rect<WR, O_GQ, W2>(vr, c.w.G2, kl, k1);
             PROF_T0(ts);
             for (int k = k1; k >= k0; k--) {
-                const double *ric = vr + (size_t)(k - k0) * WR;
+                const double *ric = vr + (size_t)(k - kl) * WR;
+                const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
                 double *fac = vf + (size_t)(k - k0) * W4;
                 const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
-                    // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x
+                    // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x ; R~, S~ of stage N-1
                     ex.seq([&](int lane) {
-                        for (int e = lane; e < 144; e += WAVE) { sm.M[cur][e] = 0.0; fac[O_PM + e] = 0.0; }
-                        if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
+                        for (int e = lane; e < 144; e += WAVE) { fac[O_PM + e] = 0.0; sm.M[cur][e] = 0.0; }
+                        if (lane >= 40 && lane < 40 + NX) { sm.pv[cur][lane - 40] = gt[6 + lane - 40]; fac[O_PV + lane - 40] = gt[6 + lane - 40]; }
+                        if (lane < 36) {
+                            FactLane &f = fl.at(lane);
+                            f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
+                            next_stage(lane, f, ricd + 36, sb);
+                        }
                     });
                     continue;
                 }
-                // ---- F0: S~ (72 entries), R~ (21 lower entries), m~ = p_{k+1} + P_{k+1} rb_k (12)
+                // ---- B: LDL' (right-looking) + one right-hand side per lane; m~
                 ex.seq([&](int lane) {
-                    const double *M = sm.M[cur];
-                    const FactLane &f = fl.at(lane);
-                    sm.St[lane] = eval_item(f.s1, M);
-                    if (lane < 29) {
-                        double v = eval_item(f.x2, M);
-                        if (f.x2_gam >= 0) v += gam[f.x2_gam];
-                        if (lane < 8) sm.St[f.x2_dst] = v;
-                        else { sm.Rt[f.x2_dst & 0xffff] = v; sm.Rt[f.x2_mirror] = v; }
-                    } else if (lane >= 32 && lane < 32 + NX) {
-                        const int i = lane - 32;
-                        double s = sm.pv[cur][i];
+                    const double *St = sm.St2[sb];
+                    double A_[6][6];
 #pragma unroll
-                        for (int j = 0; j < NX; j++) s += M[i * 12 + j] * rbv[j];
-                        sm.mt[i] = s;
-                    }
-                });
-                // ---- F1: LDL' of R~ (redundant), one right-hand side per lane; vector part
-                ex.seq([&](int lane) {
-                    double hu[6];
+                    for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = 0; j < 6; j++) hu[j] = gt[j] + P.b1[j] * sm.mt[j] + P.b2[j] * sm.mt[6 + j];
-                    double L[6][6], dd[6], dinv[6];
+                        for (int j = 0; j <= i; j++) A_[i][j] = sm.Rt[i * 6 + j];
+                    double dinv[6];
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
-                        double d = sm.Rt[j * 6 + j];
+                        dinv[j] = fast_rcp(A_[j][j]);
+                        double lj[6];
 #pragma unroll
-                        for (int r = 0; r < j; r++) d -= L[j][r] * L[j][r] * dd[r];
-                        dd[j] = d;
-                        dinv[j] = fast_rcp(d);
+                        for (int i = j + 1; i < 6; i++) lj[i] = A_[i][j] * dinv[j];
 #pragma unroll
-                        for (int i = j + 1; i < 6; i++) {
-                            double s = sm.Rt[i * 6 + j];
+                        for (int i = j + 1; i < 6; i++)
 #pragma unroll
-                            for (int r = 0; r < j; r++) s -= L[i][r] * L[j][r] * dd[r];
-                            L[i][j] = s * dinv[j];
-                        }
+                            for (int r = j + 1; r <= i; r++) A_[i][r] -= lj[i] * A_[r][j];
+#pragma unroll
+                        for (int i = j + 1; i < 6; i++) A_[i][j] = lj[i];   // L(i,j)
                     }
                     if (lane < 18) {
                         double x[6];
 #pragma unroll
                         for (int i = 0; i < 6; i++)
-                            x[i] = lane < 12 ? sm.St[i * 12 + (lane < 12 ? lane : 0)] : (i == lane - 12 ? 1.0 : 0.0);
+                            x[i] = lane < 12 ? St[i * 12 + (lane < 12 ? lane : 0)] : (i == lane - 12 ? 1.0 : 0.0);
 #pragma unroll
-                        for (int i = 0; i < 6; i++) {  // L y = rhs
+                        for (int j = 0; j < 6; j++) {          // L y = rhs, column oriented
 #pragma unroll
-                            for (int r = 0; r < i; r++) x[i] -= L[i][r] * x[r];
+                            for (int i = j + 1; i < 6; i++) x[i] -= A_[i][j] * x[j];
                         }
 #pragma unroll
                         for (int i = 0; i < 6; i++) x[i] *= dinv[i];
 #pragma unroll
-                        for (int i = 5; i >= 0; i--) {  // L' x = y
+                        for (int j = 5; j >= 0; j--) {         // L' x = y, column oriented
 #pragma unroll
-                            for (int r = i + 1; r < 6; r++) x[i] -= L[r][i] * x[r];
+                            for (int i = 0; i < j; i++) x[i] -= A_[j][i] * x[j];
                         }
                         if (lane < 12) {
 #pragma unroll
@@ -747,59 +685,74 @@ struct Engine {
 #pragma unroll
                             for (int i = 0; i < 6; i++) fac[O_RI + i * 6 + (lane - 12)] = x[i];
                         }
-                    }
-                    if (lane < NX) {
-                        double hx = gt[6 + lane];
-                        if (lane < 6) hx += sm.mt[lane];
-                        else hx += P.a12[lane - 6] * sm.mt[lane - 6] + P.a22[lane - 6] * sm.mt[lane];
-                        sm.hx[lane] = hx;  // p_j = hx_j - sum_m Kfb(m,j) hu_m is finished in F2
-                    }
-                    if (lane < 6) {
-                        double v = hu[0];
+                    } else if (lane >= 40 && lane < 40 + NX) {
+                        const int i = lane - 40;
+                        const double *Mn = sm.M[cur] + i * 12;         // row i of P_{k+1}
+                        double s = sm.pv[cur][i];
 #pragma unroll
-                        for (int j = 1; j < 6; j++) v = lane == j ? hu[j] : v;
-                        fac[O_HU + lane] = v;
+                        for (int j = 0; j < NX; j++) s += Mn[j] * rbv[j];
+                        sm.mt[i] = s;
                     }
                 });
-                // ---- F2: p_k, and P_k = H_xx + Gamma_q + A'MA - S~' Kfb   (78 unique entries)
+                // ---- CA: P_k block, then R~/S~ of stage k-1 ; h_u and p_k
                 ex.seq([&](int lane) {
-                    const double *M = sm.M[cur];
-                    const double *gq = ric, *gv = ric + 30;
-                    const FactLane &f = fl.at(lane);
-                    if (lane >= 32 && lane < 32 + NX) {
-                        const int i = lane - 32;
-                        double pj = sm.hx[i];
+                    if (lane < 36) {
+                        FactLane &f = fl.at(lane);
+                        if (k > 0) {
+                            const double *St = sm.St2[sb];
+                            const double *gq = ric, *gv = ric + 30;
+                            double sa[6], sva[6], kb[6], kvb[6];
 #pragma unroll
-                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + i] * fac[O_HU + m];
-                        sm.pv[nxt][i] = pj;
-                        fac[O_PV + i] = pj;
-                    }
-                    if (k > 0) {
-                        auto entry = [&](const Item4 &it, int i, int j, double cst, int gi) {
-                            double v = eval_item(it, M) + cst;
-                            if (i < 6) {
-                                double s = 0.0;
-#pragma unroll
-                                for (int r = 0; r < NTASK; r++) s += P.w_task[r] * gq[r * 6 + i] * gq[r * 6 + j];
-                                v += P.dt * s;
-                                if (gi >= 0) v += gam[gi];
-                            } else if (j < 6) {
-                                v += dtw5 * gv[i - 6] * gq[24 + j];
-                            } else {
-                                v += dtw5 * gv[i - 6] * gv[j - 6];
+                            for (int m = 0; m < 6; m++) {
+                                sa[m] = St[m * 12 + f.a]; sva[m] = St[m * 12 + 6 + f.a];
+                                kb[m] = sm.Kf[m * 12 + f.b]; kvb[m] = sm.Kf[m * 12 + 6 + f.b];
                             }
+                            const double ga0 = gq[f.a], ga1 = gq[6 + f.a], ga2 = gq[12 + f.a], ga3 = gq[18 + f.a], ga4 = gq[24 + f.a];
+                            const double gb0 = gq[f.b], gb1 = gq[6 + f.b], gb2 = gq[12 + f.b], gb3 = gq[18 + f.b], gb4 = gq[24 + f.b];
+                            const double gva = gv[f.a], gvb = gv[f.b];
+                            double pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4);
+                            double pqv = f.qqv + dw4 * ga4 * gvb;
+                            double pvq = f.qvq + dw4 * gva * gb4;
+                            double pvv = f.qvv + dw4 * gva * gvb + f.huv_c;
+                            if (f.a == f.b) pqq += gam[6 + f.a];
 #pragma unroll
-                            for (int m = 0; m < 6; m++) v -= sm.St[m * 12 + i] * sm.Kf[m * 12 + j];
-                            sm.M[nxt][i * 12 + j] = v;
-                            sm.M[nxt][j * 12 + i] = v;
-                            fac[O_PM + i * 12 + j] = v;
-                            fac[O_PM + j * 12 + i] = v;
-                        };
-                        entry(f.p1, f.pi1, f.pj1, f.pc1, f.pg1);
-                        if (lane < 14) entry(f.p2, f.pi2, f.pj2, f.pc2, f.pg2);
+                            for (int m = 0; m < 6; m++) {
+                                pqq -= sa[m] * kb[m]; pqv -= sa[m] * kvb[m];
+                                pvq -= sva[m] * kb[m]; pvv -= sva[m] * kvb[m];
+                            }
+                            f.mqq = pqq; f.mqv = pqv; f.mvq = pvq; f.mvv = pvv;
+                            fac[O_PM + f.a * 12 + f.b] = pqq;
+                            fac[O_PM + f.a * 12 + 6 + f.b] = pqv;
+                            fac[O_PM + (6 + f.a) * 12 + f.b] = pvq;
+                            fac[O_PM + (6 + f.a) * 12 + 6 + f.b] = pvv;
+                            double *Mo = sm.M[nxt];                        // for m~ of stage k-1 (also across chunk seams)
+                            Mo[f.a * 12 + f.b] = pqq; Mo[f.a * 12 + 6 + f.b] = pqv;
+                            Mo[(6 + f.a) * 12 + f.b] = pvq; Mo[(6 + f.a) * 12 + 6 + f.b] = pvv;
+                            next_stage(lane, f, ricd + 36, sb ^ 1);
+                        }
+                    } else if (lane >= 40 && lane < 40 + NX) {
+                        const int j = lane - 40;
+                        double hu[6];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) hu[i] = gt[i] + P.b1[i] * sm.mt[i] + P.b2[i] * sm.mt[6 + i];
+                        double hx = gt[6 + j];
+                        if (j < 6) hx += sm.mt[j];
+                        else hx += P.a12[j - 6] * sm.mt[j - 6] + P.a22[j - 6] * sm.mt[j];
+                        double pj = hx;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + j] * hu[m];
+                        sm.pv[nxt][j] = pj;
+                        fac[O_PV + j] = pj;
+                        if (j < 6) {
+                            double v = hu[0];
+#pragma unroll
+                            for (int i = 1; i < 6; i++) v = j == i ? hu[i] : v;
+                            fac[O_HU + j] = v;
+                        }
                     }
                 });
                 cur = nxt;
+                sb ^= 1;
             }
             ex.join();
             PROF_ADD(PF_SEQ_FACT, ts);

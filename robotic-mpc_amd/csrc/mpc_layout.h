@@ -150,6 +150,7 @@ struct Smem {
     double pv[2][12];
     double Rt[36];      // R~ = H_uu + Gamma_u + B'MB
     double St[72];      // S~ = H_ux + B'MA           (6x12)
+    double St2[2][72];  // S~ double buffer of the factorisation sweep (stage k read, k-1 written)
     double Kf[72];      // R~^-1 S~
     double mt[12];      // p_{k+1} + P_{k+1} rb_k
     double hx[12];      // h_x
