@@ -60,8 +60,10 @@ struct Ctx {
 // HBM pointers inside the bulk copies carry the global address space explicitly (same reason).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MPC_GLOBAL __attribute__((address_space(1)))
+#define MPC_LOCAL __attribute__((address_space(3)))
 #else
 #define MPC_GLOBAL
+#define MPC_LOCAL
 #endif
 
 // 16-byte register type of the bulk copies: a native vector (a struct here turns every load into
@@ -132,69 +134,87 @@ struct Engine {
     }
 
     // =========================================================================== chunk I/O
-    // Rectangle = columns [C0, C0+W) of stages [k_lo, k_hi] of a group with row stride LDG.
-    // The LDS copy is compact (row stride W).  W, C0, LDG even: 16-byte accesses, every lane
-    // issues its loads back to back (two register sets in flight) before touching LDS.
+    // Rectangle = columns [C0, C0+W) of stages [k_lo, k_hi] of a group with row stride LDG (HBM);
+    // the LDS copy has row stride LDL.  W, C0, LDG, LDL even: everything moves as 16-byte items,
+    // sixteen per lane in flight (counted vmcnt).  Lanes map to (row, column) with a power-of-two
+    // column pitch, so addressing is shifts and masks -- at one or four waves per simulation the
+    // copies are bound by instruction issue and latency, not by bytes.  Out-of-range lanes are
+    // clamped onto the last valid item (duplicate copies of the same value are harmless).
+    template <int W, int C0, int LDG, int LDL, bool LOAD>
+    MPC_HD void copy_rect(double *l, double *g, int k_lo, int k_hi)
+    {
+        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0 && LDL % 2 == 0, "16-byte granularity");
+        constexpr int W2h = W / 2;
+        constexpr int SH = W2h <= 1 ? 0 : (W2h <= 2 ? 1 : (W2h <= 4 ? 2 : (W2h <= 8 ? 3 : (W2h <= 16 ? 4 : (W2h <= 32 ? 5 : (W2h <= 64 ? 6 : (W2h <= 128 ? 7 : 8)))))));
+        constexpr int PITCH = 1 << SH;             // >= W2h
+        constexpr bool FLAT = (W == LDG && W == LDL);   // whole rows: one contiguous span on both sides
+        static_assert(FLAT || (PITCH >= W2h && PITCH <= WAVE), "partial rows wider than a wavefront are not needed");
+        constexpr int RPI = FLAT ? 1 : NT / PITCH;  // rows covered by one instruction group
+        // the bounds are the same in every lane; telling the compiler so keeps the copy loops scalar
+        // (a lane-divergent loop here also trips an AGPR-reload-under-empty-exec miscompile in hipcc 7.2)
+        k_lo = ex.uni(k_lo);
+        const int rows = ex.uni(k_hi - k_lo + 1);
+        if (rows <= 0) return;
+        MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(ex.uni(g) + (size_t)k_lo * LDG + C0);
+        MPC_LOCAL D2 *lb = (MPC_LOCAL D2 *)ex.uni(l);
+        PROF_T0(t0);
+        if (FLAT) {
+            const int tot = rows * W2h;
+            ex.par([&](int lane) {
+                for (int base = 0; base < tot; base += NT * 16) {
+#define MPC_AD(u) const int e##u = imin(base + u * NT + lane, tot - 1);
+#define MPC_LD(u) const D2 v##u = LOAD ? gb[e##u] : lb[e##u];
+#define MPC_ST(u)                  \
+    if (LOAD) lb[e##u] = v##u;     \
+    else gb[e##u] = v##u;
+                    MPC_REP16(MPC_AD)
+                    MPC_REP16(MPC_LD)
+                    MPC_REP16(MPC_ST)
+#undef MPC_AD
+#undef MPC_LD
+#undef MPC_ST
+                }
+            });
+            PROF_ADD(PF_IO, t0);
+            return;
+        }
+        ex.par([&](int lane) {
+            const int col = imin(lane & (PITCH - 1), W2h - 1);
+            const int r0 = lane >> SH;
+            for (int rb0 = 0; rb0 < rows; rb0 += RPI * 16) {
+#define MPC_AD(u)                                               \
+    const int row##u = imin(rb0 + u * RPI + r0, rows - 1);      \
+    MPC_GLOBAL D2 *gp##u = gb + (size_t)row##u * (LDG / 2) + col; \
+    MPC_LOCAL D2 *lp##u = lb + (size_t)row##u * (LDL / 2) + col;
+#define MPC_LD(u) const D2 v##u = LOAD ? *gp##u : *lp##u;
+#define MPC_ST(u)                  \
+    if (LOAD) *lp##u = v##u;       \
+    else *gp##u = v##u;
+                MPC_REP16(MPC_AD)
+                MPC_REP16(MPC_LD)
+                MPC_REP16(MPC_ST)
+#undef MPC_AD
+#undef MPC_LD
+#undef MPC_ST
+            }
+        });
+        PROF_ADD(PF_IO, t0);
+    }
     template <int W, int C0, int LDG>
     MPC_HD void load_rect(double *l, const double *g, int k_lo, int k_hi)
     {
-        constexpr int W2h = W / 2;
-        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
-        const int tot = (k_hi - k_lo + 1) * W2h;
-        const MPC_GLOBAL D2 *gb = (const MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
-        D2 *lb = reinterpret_cast<D2 *>(l);
-        PROF_T0(t0);
-        ex.par([&](int lane) {
-            // Sixteen individually named 16-byte registers per lane: all loads of a batch are issued
-            // back to back and retired with counted vmcnt waits.  (A local array here lands in scratch
-            // memory in the full kernel and serialises every load on `s_waitcnt vmcnt(0)`.)
-            for (int base = 0; base < tot; base += NT * 16) {
-#define MPC_LD(u)                                                  \
-    const int e##u = imin(base + u * NT + lane, tot - 1);         \
-    const int s##u = e##u / W2h;                                   \
-    const D2 r##u = gb[(size_t)s##u * (LDG / 2) + (e##u - s##u * W2h)];
-#define MPC_ST(u) lb[e##u] = r##u;
-                MPC_REP16(MPC_LD)
-                MPC_REP16(MPC_ST)
-#undef MPC_LD
-#undef MPC_ST
-            }
-        });
-        PROF_ADD(PF_IO, t0);
+        copy_rect<W, C0, LDG, W, true>(l, const_cast<double *>(g), k_lo, k_hi);
     }
-
     template <int W, int C0, int LDG>
     MPC_HD void store_rect(const double *l, double *g, int k_lo, int k_hi)
     {
-        constexpr int W2h = W / 2;
-        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
-        const int tot = (k_hi - k_lo + 1) * W2h;
-        MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
-        const D2 *lb = reinterpret_cast<const D2 *>(l);
-        PROF_T0(t0);
-        ex.par([&](int lane) {
-            for (int base = 0; base < tot; base += NT * 16) {
-#define MPC_LD(u)                                          \
-    const int e##u = imin(base + u * NT + lane, tot - 1); \
-    const D2 r##u = lb[e##u];
-#define MPC_ST(u)                      \
-    {                                  \
-        const int s_ = e##u / W2h;     \
-        gb[(size_t)s_ * (LDG / 2) + (e##u - s_ * W2h)] = r##u; \
-    }
-                MPC_REP16(MPC_LD)
-                MPC_REP16(MPC_ST)
-#undef MPC_LD
-#undef MPC_ST
-            }
-        });
-        PROF_ADD(PF_IO, t0);
+        copy_rect<W, C0, LDG, W, false>(const_cast<double *>(l), g, k_lo, k_hi);
     }
 
     MPC_HD int chunk_len(int per_stage, int halo_doubles) const
     {
         const int ch = (c.pool_n - halo_doubles) / per_stage;
-        return imax(1, imin(ch, N + 1));
+        return ex.uni(imax(1, imin(ch, N + 1)));
     }
 
     // =========================================================================== NLP pass
@@ -209,7 +229,7 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         const int W5M = 60;  // NPI, NLAM, NT
         const int CH = chunk_len(W1 + W5M + W2, 2 * (W1 + W5M));
         double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
@@ -318,41 +338,14 @@ struct Engine {
                 rc = fmax(rc, ex.reduce_max(sm.red[3]));
             }
             if (do_update) {
-                store_rect<18, 0, W1>(v1 + (size_t)(k0 - lo) * W1, c.w.G1, k0, k1, W1);
-                if (sqp_mult) store_rect<60, 0, W5>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, 60);
+                copy_rect<18, 0, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1), c.w.G1, k0, k1);
+                if (sqp_mult) copy_rect<60, 0, W5, 60, false>(const_cast<double *>(v5 + (size_t)(k0 - lo) * 60), c.w.G5, k0, k1);
             }
-            store_rect<W2_LIN, 0, W2>(v2, c.w.G2, k0, k1, W2);
+            copy_rect<W2_LIN, 0, W2, W2, false>(const_cast<double *>(v2), c.w.G2, k0, k1);
         }
         if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
         PROF_ADD(PF_NLP, t0);
         return cost;
-    }
-
-    // store_rect variant whose LDS source has a row stride different from the rectangle width
-    template <int W, int C0, int LDG>
-    MPC_HD void store_rect(const double *l, double *g, int k_lo, int k_hi, int ldl)
-    {
-        constexpr int W2h = W / 2;
-        static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0, "16-byte granularity");
-        const int tot = (k_hi - k_lo + 1) * W2h;
-        MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(g + (size_t)k_lo * LDG + C0);
-        const D2 *lb = reinterpret_cast<const D2 *>(l);
-        const int ldl2 = ldl / 2;
-        PROF_T0(t0);
-        ex.par([&](int lane) {
-            for (int base = 0; base < tot; base += NT * 16) {
-#define MPC_LD(u)                                          \
-    const int e##u = imin(base + u * NT + lane, tot - 1); \
-    const int s##u = e##u / W2h, c##u = e##u - s##u * W2h;  \
-    const D2 r##u = lb[(size_t)s##u * ldl2 + c##u];
-#define MPC_ST(u) gb[(size_t)s##u * (LDG / 2) + c##u] = r##u;
-                MPC_REP16(MPC_LD)
-                MPC_REP16(MPC_ST)
-#undef MPC_LD
-#undef MPC_ST
-            }
-        });
-        PROF_ADD(PF_IO, t0);
     }
 
     // Stationarity element (k,c) of the Lagrangian: cost gradient (+ GN Hessian * delta when
@@ -406,7 +399,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         constexpr int W3D = 78, W3R = 66, WG = 42;
         const int per = W1 + W3D + W2_LIN + W3R + WG;
         const int CH = chunk_len(per, 2 * (W1 + W3D));
@@ -544,10 +537,10 @@ struct Engine {
             nd = fmax(nd, ex.reduce_max(sm.red[2]));
             nm = fmax(nm, ex.reduce_max(sm.red[3]));
             smu += ex.reduce_sum(sm.red[4]);
-            store_rect<78, O_QW, W1>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, W1);
-            store_rect<10, 0, W2>(v2, c.w.G2, k0, k1, W2_LIN);        // r (unchanged) and y
-            store_rect<WG, O_GAM, W2>(vg, c.w.G2, k0, k1, WG);        // Gamma | gt | rb
-            store_rect<W3R, 0, W3>(v3r, c.w.G3, k0, k1, W3R);         // RG | RD | RM
+            copy_rect<78, O_QW, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1 + O_QW), c.w.G1, k0, k1);
+            copy_rect<10, 0, W2, W2_LIN, false>(const_cast<double *>(v2), c.w.G2, k0, k1);        // r (unchanged) and y
+            copy_rect<WG, O_GAM, W2, WG, false>(const_cast<double *>(vg), c.w.G2, k0, k1);        // Gamma | gt | rb
+            copy_rect<W3R, 0, W3, W3R, false>(const_cast<double *>(v3r), c.w.G3, k0, k1);         // RG | RD | RM
         }
         nrm[0] = ng; nrm[1] = nb; nrm[2] = nd; nrm[3] = nm;
         *smu_out = smu;
@@ -579,7 +572,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
         const int CH = chunk_len(WR + W4, WR);
         typename Ex::template PerLane<FactLane> fl;
@@ -772,7 +765,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         constexpr int WLT = 48, WGR = 30, WV = 24;
         const int CH = chunk_len(WLT + W3 + WGR + W4 + WV, W4);
         typename Ex::template PerLane<D2> ab;   // lanes < 12: (a12, a22) of the lane's joint
@@ -888,8 +881,8 @@ struct Engine {
                     fac[O_HU + i] = gt[i] + P.b1[i] * (pn[i] + wv[i]) + P.b2[i] * (pn[6 + i] + wv[6 + i]);
                 }
             });
-            store_rect<24, O_RM, W3>(v3 + O_RM, c.w.G3, k0, k1, W3);
-            store_rect<18, O_HU, W4>(v4 + O_HU, c.w.G4, k0, k1, W4);
+            copy_rect<24, O_RM, W3, W3, false>(const_cast<double *>(v3 + O_RM), c.w.G3, k0, k1);
+            copy_rect<18, O_HU, W4, W4, false>(const_cast<double *>(v4 + O_HU), c.w.G4, k0, k1);
         }
         PROF_ADD(PF_BWD, t0);
     }
@@ -904,7 +897,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 6;
         const int CH = chunk_len(W4 + WRB + WLT + WR + WO + WH, 0);
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
@@ -1054,13 +1047,17 @@ struct Engine {
         int it = 0, status = 1;
         double alpha = 1.0;
         for (;; it++) {
-            if (nrm[0] != nrm[0] || nrm[1] != nrm[1] || nrm[2] != nrm[2] || nrm[3] != nrm[3]) { status = 3; break; }
-            if (!(nrm[0] > tol || nrm[1] > tol || nrm[2] > tol || nrm[3] > tol)) { status = 0; break; }
-            if (it >= c.pb->qp_iter_max) { status = 1; break; }
-            if (!(alpha > 1e-12)) { status = 2; break; }
+            // every lane holds the same scalars; the decision is made uniform explicitly (scalar branch)
+            int stop = -1;
+            if (nrm[0] != nrm[0] || nrm[1] != nrm[1] || nrm[2] != nrm[2] || nrm[3] != nrm[3]) stop = 3;
+            else if (!(nrm[0] > tol || nrm[1] > tol || nrm[2] > tol || nrm[3] > tol)) stop = 0;
+            else if (it >= c.pb->qp_iter_max) stop = 1;
+            else if (!(alpha > 1e-12)) stop = 2;
+            stop = ex.uni(stop);
+            if (stop >= 0) { status = stop; break; }
             fact_pass();
             const double a_aff = forward_step_pass(S);
-            if (nc > 0) {
+            if (ex.uni(nc > 0)) {
                 const double mu_aff = (S[0] + a_aff * (S[1] + a_aff * S[2])) / nc;
                 const double tmp = mu_aff / mu;
                 const double sigma = tmp * tmp * tmp;
@@ -1090,7 +1087,7 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
-        const int Nl = N;
+        const int Nl = ex.uni(N);
         constexpr int WMW = 36;
         const int CH = chunk_len(W1 + WMW + 16, W1);
         double total = 0.0;
@@ -1197,7 +1194,7 @@ struct Engine {
         const double m0 = merit_pass(0.0, true, sqp_iter);
         double alpha = 1.0;
         while (alpha >= 0.05) {
-            if (merit_pass(alpha, false, sqp_iter) < m0) break;
+            if (ex.uni(merit_pass(alpha, false, sqp_iter) < m0)) break;
             alpha *= 0.7;
         }
         return alpha;
@@ -1234,8 +1231,8 @@ struct Engine {
                     pending = false;
                     lin_valid = true;
                 }
-                if (res4[0] < tol && res4[1] < tol && res4[2] < tol && res4[3] < tol) { status = 0; break; }
-                if (res4[0] != res4[0] || cost != cost) { status = 1; break; }
+                if (ex.uni(res4[0] < tol && res4[1] < tol && res4[2] < tol && res4[3] < tol)) { status = 0; break; }
+                if (ex.uni(res4[0] != res4[0] || cost != cost)) { status = 1; break; }
                 const int qs = ipm_solve(&it);
                 qp_iter += it;
                 if (qs != 0 && qs != 1) { status = 4; break; }
@@ -1282,7 +1279,7 @@ struct Engine {
                 if (lane < NX) sm.xhat[lane] = w.state[lane];
             });
             lin_cost = w.state[12];
-            lin_valid = w.state[25] != 0.0;
+            lin_valid = ex.uni(w.state[25] != 0.0);
         }
         for (int i = step0; i < step1; i++) {
             int sqp_iter = 0, qp_iter = 0;

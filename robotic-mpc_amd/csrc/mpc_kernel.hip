@@ -37,6 +37,21 @@ struct DevExec {
     __device__ __forceinline__ static int lane_id() { return (int)threadIdx.x; }
     __device__ __forceinline__ Smem &smem() const { return g_sm; }
     __device__ __forceinline__ double *pool() const { return g_pool; }
+    // value known to be identical in every lane -> scalar register (and scalar control flow)
+    __device__ __forceinline__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ static bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+    __device__ __forceinline__ static double uni(double v)
+    {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+    template <class T>
+    __device__ __forceinline__ static T *uni(T *p)
+    {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return (T *)(((unsigned long long)hi << 32) | lo);
+    }
     // per-lane registers that live across phases
     template <class T>
     struct PerLane {
@@ -80,7 +95,7 @@ struct DevExec {
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             tot += v;
         }
-        return tot;
+        return uni(tot);
     }
     __device__ __forceinline__ double reduce_max(const double *r)
     {
@@ -92,7 +107,7 @@ struct DevExec {
             for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
             tot = fmax(tot, v);
         }
-        return tot;
+        return uni(tot);
     }
     __device__ __forceinline__ double reduce_min(const double *r)
     {
@@ -104,7 +119,7 @@ struct DevExec {
             for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
             tot = fmin(tot, v);
         }
-        return tot;
+        return uni(tot);
     }
     // constant 100 MHz counter (s_memrealtime)
     __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
@@ -369,6 +384,16 @@ int mpcb_debug_profile(mpcb_handle *h, int inst, double *out16)
     HIPCHK(h, hipSetDevice(h->device));
     const double *src = h->d_ws + (size_t)inst * h->ws_stride + (size_t)(h->pb.N + 1) * STAGE_DOUBLES + 32;
     HIPCHK(h, hipMemcpy(out16, src, NPROF * sizeof(double), hipMemcpyDeviceToHost));
+    return MPCB_OK;
+}
+
+// Diagnostic: copy one simulation's HBM workspace to the host (layout: mpc_layout.h ws_carve).
+int mpcb_debug_workspace(mpcb_handle *h, int inst, double *out, size_t n_doubles)
+{
+    if (!h || !out || !h->ready || inst < 0 || inst >= h->pb.batch) return MPCB_EINVAL;
+    if (n_doubles > h->ws_stride) n_doubles = h->ws_stride;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(out, h->d_ws + (size_t)inst * h->ws_stride, n_doubles * sizeof(double), hipMemcpyDeviceToHost));
     return MPCB_OK;
 }
 

@@ -23,6 +23,11 @@ struct HostExec {
     double *pool_;
     Smem &smem() const { return *sm_; }
     double *pool() const { return pool_; }
+    static int uni(int v) { return v; }
+    static bool uni(bool v) { return v; }
+    static double uni(double v) { return v; }
+    template <class T>
+    static T *uni(T *p) { return p; }
     template <class T>
     struct PerLane {
         T v[WAVE * NWV];
