@@ -297,9 +297,9 @@ struct Engine {
                         for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
                     }
                 }
-                sm.red[4][lane] = csum;
+                ex.put_sum(sm.red[4], lane, csum);
             });
-            cost += ex.reduce_sum(sm.red[4]);
+            cost += ex.get_sum(sm.red[4]);
             if (res4) {
                 ex.par([&](int lane) {
                     double a_s = 0, a_e = 0, a_i = 0, a_c = 0;
@@ -330,12 +330,12 @@ struct Engine {
                         if (ci < NX && k < Nl) a_e = fmax(a_e, fabs(v2[(size_t)s * W2 + O_BD + ci]));
                     }
                     if (k0 == 0 && lane < NX) a_i = fmax(a_i, fabs(sm.xhat[lane] - v1[O_X + lane]));  // lbx_0 = ubx_0 = x_hat
-                    sm.red[0][lane] = a_s; sm.red[1][lane] = a_e; sm.red[2][lane] = a_i; sm.red[3][lane] = a_c;
+                    ex.put_max(sm.red[0], lane, a_s); ex.put_max(sm.red[1], lane, a_e); ex.put_max(sm.red[2], lane, a_i); ex.put_max(sm.red[3], lane, a_c);
                 });
-                rs = fmax(rs, ex.reduce_max(sm.red[0]));
-                re = fmax(re, ex.reduce_max(sm.red[1]));
-                ri = fmax(ri, ex.reduce_max(sm.red[2]));
-                rc = fmax(rc, ex.reduce_max(sm.red[3]));
+                rs = fmax(rs, ex.get_max(sm.red[0]));
+                re = fmax(re, ex.get_max(sm.red[1]));
+                ri = fmax(ri, ex.get_max(sm.red[2]));
+                rc = fmax(rc, ex.get_max(sm.red[3]));
             }
             if (do_update) {
                 copy_rect<18, 0, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1), c.w.G1, k0, k1);
@@ -450,9 +450,9 @@ struct Engine {
                     if (lo == 0 && lane < NX) v1[O_QW + 6 + lane] = sm.xhat[lane] - v1[O_X + lane];
                     if (hi == Nl && lane < NU) v1[(size_t)(Nl - lo) * W1 + O_QW + lane] = 0.0;
                 }
-                sm.red[5][lane] = ncl;
+                ex.put_sum(sm.red[5], lane, ncl);
             });
-            if (mode == 0) nc += ex.reduce_sum(sm.red[5]);
+            if (mode == 0) nc += ex.get_sum(sm.red[5]);
             // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -529,14 +529,14 @@ struct Engine {
                     }
                     vg[(size_t)s * WG + 30 + i] = v;
                 }
-                sm.red[0][lane] = a_g; sm.red[1][lane] = a_b; sm.red[2][lane] = a_d; sm.red[3][lane] = a_m;
-                sm.red[4][lane] = a_mu;
+                ex.put_max(sm.red[0], lane, a_g); ex.put_max(sm.red[1], lane, a_b); ex.put_max(sm.red[2], lane, a_d); ex.put_max(sm.red[3], lane, a_m);
+                ex.put_sum(sm.red[4], lane, a_mu);
             });
-            ng = fmax(ng, ex.reduce_max(sm.red[0]));
-            nb = fmax(nb, ex.reduce_max(sm.red[1]));
-            nd = fmax(nd, ex.reduce_max(sm.red[2]));
-            nm = fmax(nm, ex.reduce_max(sm.red[3]));
-            smu += ex.reduce_sum(sm.red[4]);
+            ng = fmax(ng, ex.get_max(sm.red[0]));
+            nb = fmax(nb, ex.get_max(sm.red[1]));
+            nd = fmax(nd, ex.get_max(sm.red[2]));
+            nm = fmax(nm, ex.get_max(sm.red[3]));
+            smu += ex.get_sum(sm.red[4]);
             copy_rect<78, O_QW, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1 + O_QW), c.w.G1, k0, k1);
             copy_rect<10, 0, W2, W2_LIN, false>(const_cast<double *>(v2), c.w.G2, k0, k1);        // r (unchanged) and y
             copy_rect<WG, O_GAM, W2, WG, false>(const_cast<double *>(vg), c.w.G2, k0, k1);        // Gamma | gt | rb
@@ -1022,12 +1022,12 @@ struct Engine {
                     o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
                     o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
                 }
-                sm.red[0][lane] = al; sm.red[1][lane] = a0; sm.red[2][lane] = a1; sm.red[3][lane] = a2;
+                ex.put_min(sm.red[0], lane, al); ex.put_sum(sm.red[1], lane, a0); ex.put_sum(sm.red[2], lane, a1); ex.put_sum(sm.red[3], lane, a2);
             });
-            alpha = fmin(alpha, ex.reduce_min(sm.red[0]));
-            s0 += ex.reduce_sum(sm.red[1]);
-            s1 += ex.reduce_sum(sm.red[2]);
-            s2 += ex.reduce_sum(sm.red[3]);
+            alpha = fmin(alpha, ex.get_min(sm.red[0]));
+            s0 += ex.get_sum(sm.red[1]);
+            s1 += ex.get_sum(sm.red[2]);
+            s2 += ex.get_sum(sm.red[3]);
             store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
         }
         S[0] = s0; S[1] = s1; S[2] = s2;
@@ -1151,9 +1151,9 @@ struct Engine {
                     }
                 }
                 (void)vt;
-                sm.red[0][lane] = acc;
+                ex.put_sum(sm.red[0], lane, acc);
             });
-            total += ex.reduce_sum(sm.red[0]);
+            total += ex.get_sum(sm.red[0]);
         }
         PROF_ADD(PF_MERIT, t0);
         return total;

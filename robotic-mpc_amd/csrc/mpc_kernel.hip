@@ -84,43 +84,53 @@ struct DevExec {
     {
         if (NWV > 1) __syncthreads();
     }
-    // every wave reduces all NWV segments itself: same order, same bits, no extra barrier
-    __device__ __forceinline__ double reduce_sum(const double *r)
+    // ---- reductions over the NT lanes of a simulation ------------------------------------
+    // put_*: called by every lane at the end of a par phase; the wavefront reduces its 64 values
+    // with DPP row operations (no LDS round trips) and leaves one partial per wavefront in r[].
+    // get_*: after the phase barrier, combines the NWV partials (same order in every lane).
+    template <int CTRL>
+    __device__ __forceinline__ static double dpp(double v)
     {
-        double tot = 0.0;
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ static double row_lane(double v, int l)
+    {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    }
+    template <class Op>
+    __device__ __forceinline__ static double wave_reduce(double v, Op op)
+    {
+        v = op(v, dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+        v = op(v, dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+        v = op(v, dpp<0x141>(v));   // row_half_mirror
+        v = op(v, dpp<0x140>(v));   // row_mirror: every lane of a row of 16 holds the row result
+        return op(op(row_lane(v, 0), row_lane(v, 16)), op(row_lane(v, 32), row_lane(v, 48)));
+    }
+    struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+    struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+    struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+    template <class Op>
+    __device__ __forceinline__ static void put(double *r, int lane, double v, Op op)
+    {
+        const double t = wave_reduce(v, op);
+        if ((lane & (WAVE - 1)) == 0) r[lane >> 6] = t;
+    }
+    __device__ __forceinline__ static void put_sum(double *r, int lane, double v) { put(r, lane, v, OpSum()); }
+    __device__ __forceinline__ static void put_max(double *r, int lane, double v) { put(r, lane, v, OpMax()); }
+    __device__ __forceinline__ static void put_min(double *r, int lane, double v) { put(r, lane, v, OpMin()); }
+    template <class Op>
+    __device__ __forceinline__ static double get(const double *r, Op op)
+    {
+        double tot = r[0];
 #pragma unroll
-        for (int w = 0; w < NWV; w++) {
-            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            tot += v;
-        }
+        for (int w = 1; w < NWV; w++) tot = op(tot, r[w]);
         return uni(tot);
     }
-    __device__ __forceinline__ double reduce_max(const double *r)
-    {
-        double tot = r[lane_id() & (WAVE - 1)];
-#pragma unroll
-        for (int w = 0; w < NWV; w++) {
-            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-            tot = fmax(tot, v);
-        }
-        return uni(tot);
-    }
-    __device__ __forceinline__ double reduce_min(const double *r)
-    {
-        double tot = r[lane_id() & (WAVE - 1)];
-#pragma unroll
-        for (int w = 0; w < NWV; w++) {
-            double v = r[w * WAVE + (lane_id() & (WAVE - 1))];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-            tot = fmin(tot, v);
-        }
-        return uni(tot);
-    }
+    __device__ __forceinline__ static double get_sum(const double *r) { return get(r, OpSum()); }
+    __device__ __forceinline__ static double get_max(const double *r) { return get(r, OpMax()); }
+    __device__ __forceinline__ static double get_min(const double *r) { return get(r, OpMin()); }
     // constant 100 MHz counter (s_memrealtime)
     __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
 };
@@ -297,12 +307,13 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         // wavefronts per simulation: the four SIMDs of a CU are otherwise idle at one simulation per CU
         const char *env = getenv("MPCB_WAVES_PER_SIM");
         int nw = wpc <= 1 ? 4 : (wpc <= 2 ? 2 : 1);
-        if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4)) nw = atoi(env);
+        if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) nw = atoi(env);
         h->waves_per_sim = nw;
         const int lds_bytes = h->pool_doubles * (int)sizeof(double);
         HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
     h->ready = true;
     h->next_step = 0;
@@ -328,7 +339,10 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     HIPCHK(h, hipEventRecord(h->ev0, s));
     const size_t lds = (size_t)h->pool_doubles * sizeof(double);
     const dim3 grid((unsigned)h->pb.batch);
-    if (h->waves_per_sim == 4)
+    if (h->waves_per_sim == 8)
+        hipLaunchKernelGGL(mpc_rollout_kernel<8>, grid, dim3(WAVE * 8), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
+                           h->ws_stride, out, step0, step1, h->pool_doubles);
+    else if (h->waves_per_sim == 4)
         hipLaunchKernelGGL(mpc_rollout_kernel<4>, grid, dim3(WAVE * 4), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
                            h->ws_stride, out, step0, step1, h->pool_doubles);
     else if (h->waves_per_sim == 2)
@@ -366,7 +380,8 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
 {
     if (!h) return MPCB_EINVAL;
     hipFuncAttributes a;
-    HIPCHK(h, hipFuncGetAttributes(&a, h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
+    HIPCHK(h, hipFuncGetAttributes(&a, h->waves_per_sim == 8 ? (const void *)mpc_rollout_kernel<8>
+                                       : h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
                                        : h->waves_per_sim == 2 ? (const void *)mpc_rollout_kernel<2>
                                                                : (const void *)mpc_rollout_kernel<1>));
     if (vgprs) *vgprs = a.numRegs;

@@ -27,7 +27,8 @@
 namespace mpcb {
 
 constexpr int WAVE = 64;
-constexpr int NT_MAX = 256;  // at most four wavefronts cooperate on one simulation
+constexpr int NWV_MAX = 8;    // at most eight wavefronts cooperate on one simulation
+constexpr int NT_MAX = WAVE * NWV_MAX;
 constexpr int NQ = 6;   // joints
 constexpr int NX = 12;  // state  x = [q; qdot]              (prediction_model.py:46)
 constexpr int NU = 6;   // input  u = qdot_ref                (prediction_model.py:47)
@@ -156,7 +157,7 @@ struct Smem {
     double hx[12];      // h_x
     double dx[2][12];
     double du[6];
-    double red[8][NT_MAX];
+    double red[8][NWV_MAX];   // one partial per wavefront (Ex::put_* / get_*)
     double xhat[12];    // current plant state (feedback, simulator.py:206)
     double u0[6];
     double logv[40];

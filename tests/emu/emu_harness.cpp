@@ -44,9 +44,13 @@ struct HostExec {
         for (int l = 0; l < WAVE; l++) f(l);
     }
     void join() {}
-    double reduce_sum(const double *r) { double s = 0; for (int l = 0; l < NT; l++) s += r[l]; return s; }
-    double reduce_max(const double *r) { double s = r[0]; for (int l = 1; l < NT; l++) s = fmax(s, r[l]); return s; }
-    double reduce_min(const double *r) { double s = r[0]; for (int l = 1; l < NT; l++) s = fmin(s, r[l]); return s; }
+    // lanes run one after the other here: the slot accumulates in lane order
+    static void put_sum(double *r, int lane, double v) { r[0] = lane == 0 ? v : r[0] + v; }
+    static void put_max(double *r, int lane, double v) { r[0] = lane == 0 ? v : fmax(r[0], v); }
+    static void put_min(double *r, int lane, double v) { r[0] = lane == 0 ? v : fmin(r[0], v); }
+    static double get_sum(const double *r) { return r[0]; }
+    static double get_max(const double *r) { return r[0]; }
+    static double get_min(const double *r) { return r[0]; }
     double clock() { return 0.0; }
 };
 
@@ -84,6 +88,7 @@ extern "C" int emu_run(const Problem *pb, const double *robot105, const double *
                        int step_chunk, int pool_doubles, int waves)
 {
     Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time};
+    if (waves == 8) return emu_run_t<8>(pb, robot105, params, out, step_chunk, pool_doubles);
     if (waves == 4) return emu_run_t<4>(pb, robot105, params, out, step_chunk, pool_doubles);
     if (waves == 2) return emu_run_t<2>(pb, robot105, params, out, step_chunk, pool_doubles);
     return emu_run_t<1>(pb, robot105, params, out, step_chunk, pool_doubles);
