@@ -623,7 +623,10 @@ struct Engine {
                     // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x ; R~, S~ of stage N-1
                     ex.seq([&](int lane) {
                         for (int e = lane; e < 144; e += WAVE) { fac[O_PM + e] = 0.0; sm.M[cur][e] = 0.0; }
-                        if (lane >= 40 && lane < 40 + NX) { sm.pv[cur][lane - 40] = gt[6 + lane - 40]; fac[O_PV + lane - 40] = gt[6 + lane - 40]; }
+                        if (lane >= 40 && lane < 40 + NX) {
+                            sm.pv[cur][lane - 40] = gt[6 + lane - 40]; fac[O_PV + lane - 40] = gt[6 + lane - 40];
+                            fac[O_WV + lane - 40] = 0.0;
+                        }
                         if (lane < 36) {
                             FactLane &f = fl.at(lane);
                             f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
@@ -681,10 +684,11 @@ struct Engine {
                     } else if (lane >= 40 && lane < 40 + NX) {
                         const int i = lane - 40;
                         const double *Mn = sm.M[cur] + i * 12;         // row i of P_{k+1}
-                        double s = sm.pv[cur][i];
+                        double s = 0.0;
 #pragma unroll
                         for (int j = 0; j < NX; j++) s += Mn[j] * rbv[j];
-                        sm.mt[i] = s;
+                        fac[O_WV + i] = s;                             // w_k = P_{k+1} rb_k
+                        sm.mt[i] = sm.pv[cur][i] + s;
                     }
                 });
                 // ---- CA: P_k block, then R~/S~ of stage k-1 ; h_u and p_k
@@ -767,7 +771,10 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int WLT = 48, WGR = 30, WV = 24;
-        const int CH = chunk_len(WLT + W3 + WGR + W4 + WV, W4);
+        constexpr int L3 = 114;       // LDS copy of G3 without the step: RG 0 | RD 18 | RM 42 | DLAM 66 | DT 90
+        constexpr int L4 = O_PM;      // G4 without P: K | R~^-1 | h_u | p | w
+        constexpr int C_DLAM = 66, C_DT = 90;
+        const int CH = chunk_len(WLT + L3 + WGR + L4 + WV, L4);
         typename Ex::template PerLane<D2> ab;   // lanes < 12: (a12, a22) of the lane's joint
         ex.seq([&](int lane) {
             const int j = lane % 6;
@@ -778,31 +785,33 @@ struct Engine {
         for (int k1 = Nl; k1 >= 0; k1 -= CH) {
             const int k0 = imax(k1 - CH + 1, 0), kh = imin(k1 + 1, Nl);
             double *vlt = ex.pool();                     // rows k0..k1: QLAM | QT
-            double *v3 = vlt + (size_t)CH * WLT;         // rows k0..k1: G3 full
-            double *vgr = v3 + (size_t)CH * W3;          // rows k0..k1: GT(18) | RB(12)
+            double *v3 = vlt + (size_t)CH * WLT;         // rows k0..k1: G3 without DW | DPI
+            double *vgr = v3 + (size_t)CH * L3;          // rows k0..k1: GT(18) | RB(12)
             double *vv = vgr + (size_t)CH * WGR;         // rows k0..k1: w = P_{k+1} rb (12) | g~ (12)
-            double *v4 = vv + (size_t)CH * WV;           // rows k0..kh: G4 full
+            double *v4 = vv + (size_t)CH * WV;           // rows k0..kh: G4 without P
             load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
-            load_rect<W3, 0, W3>(v3, c.w.G3, k0, k1);
+            copy_rect<66, 0, W3, L3, true>(v3, c.w.G3, k0, k1);
+            copy_rect<48, O_DLAM, W3, L3, true>(v3 + C_DLAM, c.w.G3, k0, k1);
             load_rect<WGR, O_GT, W2>(vgr, c.w.G2, k0, k1);
-            load_rect<W4, 0, W4>(v4, c.w.G4, k0, kh);
+            copy_rect<O_WV, 0, W4, L4, true>(v4, c.w.G4, k0, kh);
+            copy_rect<12, O_WV, W4, L4, true>(v4 + O_WV, c.w.G4, k0, k1);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * NB; e += NT) {
                     const int s = e / NB, j = e - s * NB, k = k0 + s;
                     if (!has_comp(Nl, k, j)) continue;
                     const double *lt = vlt + (size_t)s * WLT;
-                    double *r3 = v3 + (size_t)s * W3;
+                    double *r3 = v3 + (size_t)s * L3;
                     double gt = r3[O_RG + j];
                     if (bnd_lo(P, j) > -BOUND_INF) {
                         const double l = lt[j], t = lt[24 + j];
-                        const double rm = l * t + r3[O_DLAM + j] * r3[O_DT + j] - sigma_mu;
+                        const double rm = l * t + r3[C_DLAM + j] * r3[C_DT + j] - sigma_mu;
                         r3[O_RM + j] = rm;
                         gt += (rm + l * r3[O_RD + j]) / t;
                     }
                     if (bnd_hi(P, j) < BOUND_INF) {
                         const double l = lt[12 + j], t = lt[36 + j];
-                        const double rm = l * t + r3[O_DLAM + 12 + j] * r3[O_DT + 12 + j] - sigma_mu;
+                        const double rm = l * t + r3[C_DLAM + 12 + j] * r3[C_DT + 12 + j] - sigma_mu;
                         r3[O_RM + 12 + j] = rm;
                         gt -= (rm + l * r3[O_RD + 12 + j]) / t;
                     }
@@ -814,14 +823,12 @@ struct Engine {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 24; e += NT) {
                     const int s = e / 24, i = e - s * 24, k = k0 + s;
-                    const double *gt = vgr + (size_t)s * WGR, *rbv = gt + 18;
-                    const double *fac = v4 + (size_t)s * W4;
+                    const double *gt = vgr + (size_t)s * WGR;
+                    const double *fac = v4 + (size_t)s * L4;
                     double v = 0.0;
                     if (k < Nl) {
                         if (i < 12) {
-                            const double *Mn = fac + W4 + O_PM + i * 12;
-#pragma unroll
-                            for (int j = 0; j < NX; j++) v += Mn[j] * rbv[j];
+                            v = fac[O_WV + i];                 // P_{k+1} rb_k, left by the factorisation
                         } else {
                             const int j = i - 12;
                             v = gt[6 + j];
@@ -836,7 +843,7 @@ struct Engine {
             for (int k = k1; k >= k0; k--) {
                 const double *gt = vgr + (size_t)(k - k0) * WGR;
                 const double *wv = vv + (size_t)(k - k0) * WV;
-                double *fac = v4 + (size_t)(k - k0) * W4;
+                double *fac = v4 + (size_t)(k - k0) * L4;
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
                     ex.seq([&](int lane) {
@@ -876,13 +883,13 @@ struct Engine {
                     const int s = e / 6, i = e - s * 6, k = k0 + s;
                     if (k >= Nl) continue;
                     const double *gt = vgr + (size_t)s * WGR, *wv = vv + (size_t)s * WV;
-                    double *fac = v4 + (size_t)s * W4;
-                    const double *pn = fac + W4 + O_PV;
+                    double *fac = v4 + (size_t)s * L4;
+                    const double *pn = fac + L4 + O_PV;
                     fac[O_HU + i] = gt[i] + P.b1[i] * (pn[i] + wv[i]) + P.b2[i] * (pn[6 + i] + wv[6 + i]);
                 }
             });
-            copy_rect<24, O_RM, W3, W3, false>(const_cast<double *>(v3 + O_RM), c.w.G3, k0, k1);
-            copy_rect<18, O_HU, W4, W4, false>(const_cast<double *>(v4 + O_HU), c.w.G4, k0, k1);
+            copy_rect<24, O_RM, W3, L3, false>(const_cast<double *>(v3 + O_RM), c.w.G3, k0, k1);
+            copy_rect<18, O_HU, W4, L4, false>(const_cast<double *>(v4 + O_HU), c.w.G4, k0, k1);
         }
         PROF_ADD(PF_BWD, t0);
     }
@@ -892,6 +899,7 @@ struct Engine {
     // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.  Only the state recursion
     // dx_{k+1} = A dx_k - B (Kfb dx_k + Rinv h_u) + rb_k is sequential (one phase per stage);
     // Rinv h_u before and du_k, dpi_{k-1} = P_k dx_k + p_k after it are chunk-parallel.
+    template <bool AFFINE>
     MPC_PASS double forward_step_pass(double *S)
     {
         PROF_T0(t0);
@@ -899,7 +907,10 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 6;
-        const int CH = chunk_len(W4 + WRB + WLT + WR + WO + WH, 0);
+        // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
+        // K, R~^-1, h_u (no p, no P) and leaves only dlam, dt behind for the corrector
+        constexpr int LF = AFFINE ? O_PV : W4;
+        const int CH = chunk_len(LF + WRB + WLT + WR + WO + WH, 0);
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
         typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
         ex.seq([&](int lane) {
@@ -914,12 +925,12 @@ struct Engine {
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl);
             double *v4 = ex.pool();                   // rows k0..k1, G4
-            double *vrb = v4 + (size_t)CH * W4;       // RB
+            double *vrb = v4 + (size_t)CH * LF;       // RB
             double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
             double *vr = vlt + (size_t)CH * WLT;      // RD | RM
             double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
             double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6)
-            load_rect<W4, 0, W4>(v4, c.w.G4, k0, k1);
+            load_rect<LF, 0, W4>(v4, c.w.G4, k0, k1);
             load_rect<WRB, O_RB, W2>(vrb, c.w.G2, k0, k1);
             load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
             load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
@@ -927,7 +938,7 @@ struct Engine {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 6; e += NT) {
                     const int s = e / 6, i = e - s * 6;
-                    const double *fac = v4 + (size_t)s * W4;
+                    const double *fac = v4 + (size_t)s * LF;
                     double v = 0.0;
 #pragma unroll
                     for (int m = 0; m < 6; m++) v += fac[O_RI + i * 6 + m] * fac[O_HU + m];
@@ -937,7 +948,7 @@ struct Engine {
             PROF_T0(ts);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
-                const double *fac = v4 + (size_t)(k - k0) * W4;
+                const double *fac = v4 + (size_t)(k - k0) * LF;
                 double *o = vo + (size_t)(k - k0) * WO;
                 ex.seq([&](int lane) {
                     if (lane < NX) {
@@ -970,7 +981,7 @@ struct Engine {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 18; e += NT) {
                     const int s = e / 18, ci = e - s * 18, k = k0 + s;
-                    const double *fac = v4 + (size_t)s * W4;
+                    const double *fac = v4 + (size_t)s * LF;
                     double *o = vo + (size_t)s * WO;
                     const double *dxk = o + 6;
                     double v = 0.0;
@@ -982,7 +993,7 @@ struct Engine {
                             v = -v;
                         }
                         o[ci] = v;                      // du_k (stage N has no input: 0)
-                    } else {
+                    } else if (!AFFINE) {
                         const int j = ci - 6;
                         if (k >= 1) {
                             v = fac[O_PV + j];
@@ -1028,7 +1039,8 @@ struct Engine {
             s0 += ex.get_sum(sm.red[1]);
             s1 += ex.get_sum(sm.red[2]);
             s2 += ex.get_sum(sm.red[3]);
-            store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
+            if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
+            else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
         }
         S[0] = s0; S[1] = s1; S[2] = s2;
         PROF_ADD(PF_FWD, t0);
@@ -1056,13 +1068,14 @@ struct Engine {
             stop = ex.uni(stop);
             if (stop >= 0) { status = stop; break; }
             fact_pass();
-            const double a_aff = forward_step_pass(S);
-            if (ex.uni(nc > 0)) {
+            const bool has_bounds = ex.uni(nc > 0);
+            const double a_aff = has_bounds ? forward_step_pass<true>(S) : forward_step_pass<false>(S);
+            if (has_bounds) {
                 const double mu_aff = (S[0] + a_aff * (S[1] + a_aff * S[2])) / nc;
                 const double tmp = mu_aff / mu;
                 const double sigma = tmp * tmp * tmp;
                 corrector_bwd_pass(sigma * mu);
-                alpha = forward_step_pass(S);
+                alpha = forward_step_pass<false>(S);
             } else {
                 alpha = a_aff;
             }

@@ -59,12 +59,13 @@ constexpr int O_DW = 66;    // Newton step [du; dq; dqdot] (18)
 constexpr int O_DPI = 84;   // step of the multiplier of dynamics k-1 -> k (12)   (note the shift)
 constexpr int O_DLAM = 96, O_DT = 120;
 // ---- G4 FACT ----------------------------------------------------------------------
-constexpr int W4 = 272;
+constexpr int W4 = 282;
 constexpr int O_K = 0;      // Kfb = R~^-1 S~ (6x12)
 constexpr int O_RI = 72;    // R~^-1 (6x6)
 constexpr int O_HU = 108;   // h_u (6)
 constexpr int O_PV = 114;   // p_k (12)
-constexpr int O_PM = 128;   // P_k (12x12)
+constexpr int O_WV = 126;   // w_k = P_{k+1} rb_k (12): reused by the corrector's backward solve
+constexpr int O_PM = 138;   // P_k (12x12)
 // ---- G5 SQPX ----------------------------------------------------------------------
 constexpr int W5 = 116;
 constexpr int O_NPI = 0, O_NLAM = 12, O_NT = 36, O_TX = 60, O_TU = 72, O_MW = 78;  // MW: dyn 12 + ineq 24
