@@ -775,11 +775,16 @@ struct Engine {
         constexpr int L4 = O_PM;      // G4 without P: K | R~^-1 | h_u | p | w
         constexpr int C_DLAM = 66, C_DT = 90;
         const int CH = chunk_len(WLT + L3 + WGR + L4 + WV, L4);
-        typename Ex::template PerLane<D2> ab;   // lanes < 12: (a12, a22) of the lane's joint
+        typename Ex::template PerLane<D2> ab;       // lanes < 12: (a12, a22) of the lane's joint
+        typename Ex::template PerLane<double> pr;   // lanes < 12: p_{k+1}[lane], carried from stage to stage
+        double b1r[6], b2r[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { b1r[i] = P.b1[i]; b2r[i] = P.b2[i]; }
         ex.seq([&](int lane) {
             const int j = lane % 6;
             D2 v; v.x = P.a12[j]; v.y = P.a22[j];
             ab.at(lane) = v;
+            pr.at(lane) = 0.0;
         });
         int cur = 0;
         for (int k1 = Nl; k1 >= 0; k1 -= CH) {
@@ -830,10 +835,12 @@ struct Engine {
                         if (i < 12) {
                             v = fac[O_WV + i];                 // P_{k+1} rb_k, left by the factorisation
                         } else {
+                            // c_j: everything in p_k = c + Acl' p_{k+1} that does not depend on p_{k+1}
                             const int j = i - 12;
-                            v = gt[6 + j];
+                            const double *w = fac + O_WV;
+                            v = gt[6 + j] + (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
 #pragma unroll
-                            for (int m = 0; m < 6; m++) v -= fac[O_K + m * 12 + j] * gt[m];
+                            for (int m = 0; m < 6; m++) v -= fac[O_K + m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
                         }
                     }
                     vv[(size_t)s * WV + i] = v;
@@ -847,28 +854,33 @@ struct Engine {
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
                     ex.seq([&](int lane) {
-                        if (lane < NX) { sm.pv[cur][lane] = gt[6 + lane]; fac[O_PV + lane] = gt[6 + lane]; }
+                        if (lane < NX) {
+                            const double v = gt[6 + lane];
+                            pr.at(lane) = v; ex.share(sm.pv[cur], lane, v);
+                            fac[O_PV + lane] = v;
+                        }
                     });
                     continue;
                 }
+                // p_k = c_k + Acl' p_{k+1}: p_{k+1} travels lane to lane in registers (no LDS round trip)
                 ex.seq([&](int lane) {
+                    const double mine = pr.at(lane);
+                    double pn[12];
+#pragma unroll
+                    for (int i = 0; i < NX; i++) pn[i] = ex.gather(sm.pv[cur], i, mine);
+                    const double oq = ex.shr6(sm.pv[cur], lane, mine);   // lanes 6..11: p_{k+1}[lane - 6]
                     if (lane < NX) {
                         const int j = lane;
-                        double mt[12];
-#pragma unroll
-                        for (int i = 0; i < NX; i++) mt[i] = sm.pv[cur][i] + wv[i];
-                        double acc = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 6; i++) acc += fac[O_K + i * 12 + j] * (P.b1[i] * mt[i] + P.b2[i] * mt[6 + i]);
-                        double own = mt[0], oq = mt[0];
-#pragma unroll
-                        for (int i = 1; i < NX; i++) own = j == i ? mt[i] : own;
-#pragma unroll
-                        for (int i = 1; i < 6; i++) oq = (j - 6) == i ? mt[i] : oq;
                         const D2 c2 = ab.at(lane);
-                        const double at = j < 6 ? own : c2.x * oq + c2.y * own;
-                        const double pj = wv[12 + j] + (at - acc);
-                        sm.pv[nxt][j] = pj;
+                        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 6; i += 2) {
+                            acc0 += fac[O_K + i * 12 + j] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
+                            acc1 += fac[O_K + (i + 1) * 12 + j] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
+                        }
+                        const double at = j < 6 ? mine : c2.x * oq + c2.y * mine;
+                        const double pj = wv[12 + j] + (at - (acc0 + acc1));
+                        pr.at(lane) = pj; ex.share(sm.pv[nxt], lane, pj);
                         fac[O_PV + j] = pj;
                     }
                 });
@@ -906,20 +918,22 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
-        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 6;
+        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 18;
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
         // K, R~^-1, h_u (no p, no P) and leaves only dlam, dt behind for the corrector
         constexpr int LF = AFFINE ? O_PV : W4;
         const int CH = chunk_len(LF + WRB + WLT + WR + WO + WH, 0);
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
         typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
+        typename Ex::template PerLane<double> dxr;  // lanes < 12: dx_k[lane], carried from stage to stage
         ex.seq([&](int lane) {
             const int j = lane % 6;
             D2 v; v.x = P.a12[j]; v.y = P.a22[j];
             ab.at(lane) = v;
             D2 u; u.x = P.b1[j]; u.y = P.b2[j];
             bb.at(lane) = u;
-            if (lane < NX) sm.dx[0][lane] = 0.0;  // dx_0 = 0: x_0 is pinned by the init pass
+            dxr.at(lane) = 0.0;                    // dx_0 = 0: x_0 is pinned by the init pass
+            if (lane < NX) ex.share(sm.dx[0], lane, 0.0);
         });
         int cur = 0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
@@ -934,6 +948,8 @@ struct Engine {
             load_rect<WRB, O_RB, W2>(vrb, c.w.G2, k0, k1);
             load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
             load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
+            // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
+            // does not depend on dx_k
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 6; e += NT) {
@@ -942,7 +958,10 @@ struct Engine {
                     double v = 0.0;
 #pragma unroll
                     for (int m = 0; m < 6; m++) v += fac[O_RI + i * 6 + m] * fac[O_HU + m];
-                    vh[(size_t)s * WH + i] = v;
+                    double *h = vh + (size_t)s * WH;
+                    h[i] = v;
+                    h[6 + i] = vrb[(size_t)s * WRB + i] - P.b1[i] * v;
+                    h[12 + i] = vrb[(size_t)s * WRB + 6 + i] - P.b2[i] * v;
                 }
             });
             PROF_T0(ts);
@@ -950,26 +969,28 @@ struct Engine {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
                 double *o = vo + (size_t)(k - k0) * WO;
+                // dx_{k+1} = e_k + A dx_k - B K dx_k: dx_k travels lane to lane in registers
                 ex.seq([&](int lane) {
+                    const double own = dxr.at(lane);
+                    double dxv[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) dxv[j] = ex.gather(sm.dx[cur], j, own);
+                    const double ov = ex.shl6(sm.dx[cur], lane, own);   // lanes 0..5: dx_k[6 + lane]
                     if (lane < NX) {
                         const int i = lane < 6 ? lane : lane - 6;
-                        double dxv[12];
-#pragma unroll
-                        for (int j = 0; j < NX; j++) dxv[j] = sm.dx[cur][j];
-                        double own = dxv[0], ov = dxv[6];
-#pragma unroll
-                        for (int j = 1; j < NX; j++) own = lane == j ? dxv[j] : own;
-#pragma unroll
-                        for (int j = 1; j < 6; j++) ov = i == j ? dxv[6 + j] : ov;
                         o[6 + lane] = own;   // dx_k
                         if (k < Nl) {
-                            double s = vh[(size_t)(k - k0) * WH + i];
+                            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NX; j++) s += fac[O_K + i * 12 + j] * dxv[j];
-                            const double du = -s;
+                            for (int j = 0; j < NX; j += 2) {
+                                s0 += fac[O_K + i * 12 + j] * dxv[j];
+                                s1 += fac[O_K + i * 12 + j + 1] * dxv[j + 1];
+                            }
+                            const double kd = s0 + s1;
                             const D2 a = ab.at(lane), b = bb.at(lane);
-                            const double v = lane < 6 ? own + a.x * ov + b.x * du : a.y * own + b.y * du;
-                            sm.dx[nxt][lane] = v + vrb[(size_t)(k - k0) * WRB + lane];
+                            const double v = vh[(size_t)(k - k0) * WH + 6 + lane] +
+                                             (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                            dxr.at(lane) = v; ex.share(sm.dx[nxt], lane, v);
                         }
                     }
                 });

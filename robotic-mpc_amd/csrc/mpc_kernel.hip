@@ -84,6 +84,14 @@ struct DevExec {
     {
         if (NWV > 1) __syncthreads();
     }
+    // ---- values handed from lane to lane between consecutive seq phases (registers, no LDS) ----
+    // share(): publish this lane's value for the next phase (a register stays a register here);
+    // gather(j): the value lane j published; shl6 / shr6: the value of lane + 6 / lane - 6
+    // (DPP row shifts, rows of 16 lanes; used by lanes < 12 only).
+    __device__ __forceinline__ static void share(double *, int, double) {}
+    __device__ __forceinline__ static double gather(const double *, int j, double mine) { return row_lane(mine, j); }
+    __device__ __forceinline__ static double shl6(const double *, int, double mine) { return dpp<0x106>(mine); }
+    __device__ __forceinline__ static double shr6(const double *, int, double mine) { return dpp<0x116>(mine); }
     // ---- reductions over the NT lanes of a simulation ------------------------------------
     // put_*: called by every lane at the end of a par phase; the wavefront reduces its 64 values
     // with DPP row operations (no LDS round trips) and leaves one partial per wavefront in r[].

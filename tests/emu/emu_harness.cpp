@@ -44,6 +44,11 @@ struct HostExec {
         for (int l = 0; l < WAVE; l++) f(l);
     }
     void join() {}
+    // lane-to-lane hand-over between seq phases: through the (double-buffered) slot array here
+    static void share(double *slot, int lane, double v) { slot[lane] = v; }
+    static double gather(const double *slot, int j, double) { return slot[j]; }
+    static double shl6(const double *slot, int lane, double) { return lane + 6 < 12 ? slot[lane + 6] : 0.0; }
+    static double shr6(const double *slot, int lane, double) { return lane >= 6 && lane < 12 ? slot[lane - 6] : 0.0; }
     // lanes run one after the other here: the slot accumulates in lane order
     static void put_sum(double *r, int lane, double v) { r[0] = lane == 0 ? v : r[0] + v; }
     static void put_max(double *r, int lane, double v) { r[0] = lane == 0 ? v : fmax(r[0], v); }
