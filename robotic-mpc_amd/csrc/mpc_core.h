@@ -140,8 +140,9 @@ struct Engine {
     // column pitch, so addressing is shifts and masks -- at one or four waves per simulation the
     // copies are bound by instruction issue and latency, not by bytes.  Out-of-range lanes are
     // clamped onto the last valid item (duplicate copies of the same value are harmless).
-    template <int W, int C0, int LDG, int LDL, bool LOAD>
-    MPC_HD void copy_rect(double *l, double *g, int k_lo, int k_hi)
+    // The lanes' share of one rectangle copy: NL lanes (numbered 0..NL-1) take part, no barrier.
+    template <int W, int C0, int LDG, int LDL, bool LOAD, int NL>
+    MPC_HD void copy_lanes(double *l, double *g, int k_lo, int k_hi, int lane)
     {
         static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0 && LDL % 2 == 0, "16-byte granularity");
         constexpr int W2h = W / 2;
@@ -149,7 +150,8 @@ struct Engine {
         constexpr int PITCH = 1 << SH;             // >= W2h
         constexpr bool FLAT = (W == LDG && W == LDL);   // whole rows: one contiguous span on both sides
         static_assert(FLAT || (PITCH >= W2h && PITCH <= WAVE), "partial rows wider than a wavefront are not needed");
-        constexpr int RPI = FLAT ? 1 : NT / PITCH;  // rows covered by one instruction group
+        static_assert(NL % WAVE == 0, "whole wavefronts");
+        constexpr int RPI = FLAT ? 1 : NL / PITCH;  // rows covered by one instruction group
         // the bounds are the same in every lane; telling the compiler so keeps the copy loops scalar
         // (a lane-divergent loop here also trips an AGPR-reload-under-empty-exec miscompile in hipcc 7.2)
         k_lo = ex.uni(k_lo);
@@ -157,31 +159,26 @@ struct Engine {
         if (rows <= 0) return;
         MPC_GLOBAL D2 *gb = (MPC_GLOBAL D2 *)(ex.uni(g) + (size_t)k_lo * LDG + C0);
         MPC_LOCAL D2 *lb = (MPC_LOCAL D2 *)ex.uni(l);
-        PROF_T0(t0);
         if (FLAT) {
             const int tot = rows * W2h;
-            ex.par([&](int lane) {
-                for (int base = 0; base < tot; base += NT * 16) {
-#define MPC_AD(u) const int e##u = imin(base + u * NT + lane, tot - 1);
+            for (int base = 0; base < tot; base += NL * 16) {
+#define MPC_AD(u) const int e##u = imin(base + u * NL + lane, tot - 1);
 #define MPC_LD(u) const D2 v##u = LOAD ? gb[e##u] : lb[e##u];
 #define MPC_ST(u)                  \
     if (LOAD) lb[e##u] = v##u;     \
     else gb[e##u] = v##u;
-                    MPC_REP16(MPC_AD)
-                    MPC_REP16(MPC_LD)
-                    MPC_REP16(MPC_ST)
+                MPC_REP16(MPC_AD)
+                MPC_REP16(MPC_LD)
+                MPC_REP16(MPC_ST)
 #undef MPC_AD
 #undef MPC_LD
 #undef MPC_ST
-                }
-            });
-            PROF_ADD(PF_IO, t0);
+            }
             return;
         }
-        ex.par([&](int lane) {
-            const int col = imin(lane & (PITCH - 1), W2h - 1);
-            const int r0 = lane >> SH;
-            for (int rb0 = 0; rb0 < rows; rb0 += RPI * 16) {
+        const int col = imin(lane & (PITCH - 1), W2h - 1);
+        const int r0 = lane >> SH;
+        for (int rb0 = 0; rb0 < rows; rb0 += RPI * 16) {
 #define MPC_AD(u)                                               \
     const int row##u = imin(rb0 + u * RPI + r0, rows - 1);      \
     MPC_GLOBAL D2 *gp##u = gb + (size_t)row##u * (LDG / 2) + col; \
@@ -190,14 +187,19 @@ struct Engine {
 #define MPC_ST(u)                  \
     if (LOAD) *lp##u = v##u;       \
     else *gp##u = v##u;
-                MPC_REP16(MPC_AD)
-                MPC_REP16(MPC_LD)
-                MPC_REP16(MPC_ST)
+            MPC_REP16(MPC_AD)
+            MPC_REP16(MPC_LD)
+            MPC_REP16(MPC_ST)
 #undef MPC_AD
 #undef MPC_LD
 #undef MPC_ST
-            }
-        });
+        }
+    }
+    template <int W, int C0, int LDG, int LDL, bool LOAD>
+    MPC_HD void copy_rect(double *l, double *g, int k_lo, int k_hi)
+    {
+        PROF_T0(t0);
+        ex.par([&](int lane) { copy_lanes<W, C0, LDG, LDL, LOAD, NT>(l, g, k_lo, k_hi, lane); });
         PROF_ADD(PF_IO, t0);
     }
     template <int W, int C0, int LDG>
@@ -574,7 +576,7 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
-        const int CH = chunk_len(WR + W4, WR);
+        const int CH = chunk_len(2 * (WR + W4), 2 * WR);
         typename Ex::template PerLane<FactLane> fl;
         ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
@@ -606,13 +608,19 @@ struct Engine {
             f.qvv = cq * f.a12b + cv * f.a22b;
             (void)lane;
         };
-        int cur = 0, sb = 0;
-        for (int k1 = Nl; k1 >= 0; k1 -= CH) {
+        // Two chunks in flight: while wavefront 0 runs the recursion on chunk c, the other wavefronts
+        // fetch the inputs of chunk c+1 and write the factor of chunk c-1 back (Ex::overlap).
+        int cur = 0, sb = 0, bsel = 0;
+        const size_t buf = (size_t)(CH + 1) * WR + (size_t)CH * W4;
+        load_rect<WR, O_GQ, W2>(ex.pool(), c.w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
+        for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
             const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
-            double *vr = ex.pool();                      // rows kl..k1 (one halo row below: Gamma of stage k0-1)
+            double *vr = ex.pool() + (size_t)bsel * buf; // rows kl..k1 (one halo row below: Gamma of stage k0-1)
             double *vf = vr + (size_t)(CH + 1) * WR;     // rows k0..k1, W4
-            load_rect<WR, O_GQ, W2>(vr, c.w.G2, kl, k1);
+            double *vr_n = ex.pool() + (size_t)(bsel ^ 1) * buf, *vf_p = vr_n + (size_t)(CH + 1) * WR;
+            const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);
             PROF_T0(ts);
+            ex.overlap([&]() {
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
@@ -751,9 +759,13 @@ struct Engine {
                 cur = nxt;
                 sb ^= 1;
             }
-            ex.join();
+            }, [&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_n, c.w.G2, nkl, nk1, lane);
+                if (k1 < Nl) copy_lanes<W4, 0, W4, W4, false, NL>(vf_p, c.w.G4, k1 + 1, k1 + CH, lane);
+            });
             PROF_ADD(PF_SEQ_FACT, ts);
-            store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
+            if (k0 == 0) store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
         }
         PROF_ADD(PF_FACT, t0);
     }
@@ -770,11 +782,16 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
-        constexpr int WLT = 48, WGR = 30, WV = 24;
-        constexpr int L3 = 114;       // LDS copy of G3 without the step: RG 0 | RD 18 | RM 42 | DLAM 66 | DT 90
-        constexpr int L4 = O_PM;      // G4 without P: K | R~^-1 | h_u | p | w
-        constexpr int C_DLAM = 66, C_DT = 90;
-        const int CH = chunk_len(WLT + L3 + WGR + L4 + WV, L4);
+        // LDS record of a stage: inputs | scratch | outputs.  Two chunks in flight (see fact_pass).
+        constexpr int WLT = 48;                  // QLAM | QT
+        constexpr int L3 = 90;                   // RG 0 | RD 18 | DLAM 42 | DT 66  (G3 without RM and the step)
+        constexpr int C_DLAM = 42, C_DT = 66;
+        constexpr int WGR = 30;                  // GT 0 (rebuilt in place) | RB 18
+        constexpr int WK = 72, WW = 12;          // Kfb ; w = P_{k+1} rb_k
+        constexpr int WC = 12;                   // c_k: the part of p_k that does not depend on p_{k+1}
+        constexpr int WRM = 24, WHP = 18;        // outputs: RM ; h_u (6) | p (12)
+        constexpr int PER = WLT + L3 + WGR + WK + WW + WC + WRM + WHP;
+        const int CH = chunk_len(2 * PER, 0);
         typename Ex::template PerLane<D2> ab;       // lanes < 12: (a12, a22) of the lane's joint
         typename Ex::template PerLane<double> pr;   // lanes < 12: p_{k+1}[lane], carried from stage to stage
         double b1r[6], b2r[6];
@@ -786,79 +803,87 @@ struct Engine {
             ab.at(lane) = v;
             pr.at(lane) = 0.0;
         });
-        int cur = 0;
-        for (int k1 = Nl; k1 >= 0; k1 -= CH) {
-            const int k0 = imax(k1 - CH + 1, 0), kh = imin(k1 + 1, Nl);
-            double *vlt = ex.pool();                     // rows k0..k1: QLAM | QT
-            double *v3 = vlt + (size_t)CH * WLT;         // rows k0..k1: G3 without DW | DPI
-            double *vgr = v3 + (size_t)CH * L3;          // rows k0..k1: GT(18) | RB(12)
-            double *vv = vgr + (size_t)CH * WGR;         // rows k0..k1: w = P_{k+1} rb (12) | g~ (12)
-            double *v4 = vv + (size_t)CH * WV;           // rows k0..kh: G4 without P
-            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
-            copy_rect<66, 0, W3, L3, true>(v3, c.w.G3, k0, k1);
-            copy_rect<48, O_DLAM, W3, L3, true>(v3 + C_DLAM, c.w.G3, k0, k1);
-            load_rect<WGR, O_GT, W2>(vgr, c.w.G2, k0, k1);
-            copy_rect<O_WV, 0, W4, L4, true>(v4, c.w.G4, k0, kh);
-            copy_rect<12, O_WV, W4, L4, true>(v4 + O_WV, c.w.G4, k0, k1);
+        auto carve = [&](int sel, double *&vlt, double *&v3, double *&vgr, double *&vk, double *&vw, double *&vc, double *&orm,
+                         double *&ohp) {
+            vlt = ex.pool() + (size_t)sel * CH * PER;
+            v3 = vlt + (size_t)CH * WLT; vgr = v3 + (size_t)CH * L3; vk = vgr + (size_t)CH * WGR;
+            vw = vk + (size_t)CH * WK; vc = vw + (size_t)CH * WW; orm = vc + (size_t)CH * WC; ohp = orm + (size_t)CH * WRM;
+        };
+        int cur = 0, bsel = 0;
+        {
+            double *vlt, *v3, *vgr, *vk, *vw, *vc, *orm, *ohp;
+            carve(0, vlt, v3, vgr, vk, vw, vc, orm, ohp);
+            const int f0 = imax(Nl - CH + 1, 0);
+            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, f0, Nl);
+            copy_rect<42, 0, W3, L3, true>(v3, c.w.G3, f0, Nl);
+            copy_rect<48, O_DLAM, W3, L3, true>(v3 + C_DLAM, c.w.G3, f0, Nl);
+            load_rect<WGR, O_GT, W2>(vgr, c.w.G2, f0, Nl);
+            load_rect<WK, O_K, W4>(vk, c.w.G4, f0, Nl);
+            load_rect<WW, O_WV, W4>(vw, c.w.G4, f0, Nl);
+        }
+        for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
+            const int k0 = imax(k1 - CH + 1, 0);
+            double *vlt, *v3, *vgr, *vk, *vw, *vc, *orm, *ohp;
+            carve(bsel, vlt, v3, vgr, vk, vw, vc, orm, ohp);
+            double *nlt, *n3, *ngr, *nk, *nw, *nc_, *prm, *php;   // other buffer: next inputs, previous outputs
+            carve(bsel ^ 1, nlt, n3, ngr, nk, nw, nc_, prm, php);
+            const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0);
+            // centering corrector: rm and the condensed gradient gt of every bounded component
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * NB; e += NT) {
                     const int s = e / NB, j = e - s * NB, k = k0 + s;
-                    if (!has_comp(Nl, k, j)) continue;
                     const double *lt = vlt + (size_t)s * WLT;
-                    double *r3 = v3 + (size_t)s * L3;
-                    double gt = r3[O_RG + j];
-                    if (bnd_lo(P, j) > -BOUND_INF) {
-                        const double l = lt[j], t = lt[24 + j];
-                        const double rm = l * t + r3[C_DLAM + j] * r3[C_DT + j] - sigma_mu;
-                        r3[O_RM + j] = rm;
-                        gt += (rm + l * r3[O_RD + j]) / t;
+                    const double *r3 = v3 + (size_t)s * L3;
+                    double *rmo = orm + (size_t)s * WRM;
+                    double gt = r3[j], rml = 0.0, rmu = 0.0;
+                    if (has_comp(Nl, k, j)) {
+                        if (bnd_lo(P, j) > -BOUND_INF) {
+                            const double l = lt[j], t = lt[24 + j];
+                            rml = l * t + r3[C_DLAM + j] * r3[C_DT + j] - sigma_mu;
+                            gt += (rml + l * r3[18 + j]) / t;
+                        }
+                        if (bnd_hi(P, j) < BOUND_INF) {
+                            const double l = lt[12 + j], t = lt[36 + j];
+                            rmu = l * t + r3[C_DLAM + 12 + j] * r3[C_DT + 12 + j] - sigma_mu;
+                            gt -= (rmu + l * r3[18 + 12 + j]) / t;
+                        }
+                        vgr[(size_t)s * WGR + j] = gt;
                     }
-                    if (bnd_hi(P, j) < BOUND_INF) {
-                        const double l = lt[12 + j], t = lt[36 + j];
-                        const double rm = l * t + r3[C_DLAM + 12 + j] * r3[C_DT + 12 + j] - sigma_mu;
-                        r3[O_RM + 12 + j] = rm;
-                        gt -= (rm + l * r3[O_RD + 12 + j]) / t;
-                    }
-                    vgr[(size_t)s * WGR + j] = gt;
+                    rmo[j] = rml; rmo[12 + j] = rmu;
                 }
             });
-            // chunk-parallel: w_k = P_{k+1} rb_k and g~_k = gt_x - Kfb' gt_u
+            // c_k = gt_x + A' w - Kfb' (gt_u + B' w): all of p_k = c_k + Acl' p_{k+1} that is known up front
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 24; e += NT) {
-                    const int s = e / 24, i = e - s * 24, k = k0 + s;
-                    const double *gt = vgr + (size_t)s * WGR;
-                    const double *fac = v4 + (size_t)s * L4;
+                for (int e = lane; e < rows * NX; e += NT) {
+                    const int s = e / NX, j = e - s * NX, k = k0 + s;
+                    const double *gt = vgr + (size_t)s * WGR, *w = vw + (size_t)s * WW, *kf = vk + (size_t)s * WK;
                     double v = 0.0;
                     if (k < Nl) {
-                        if (i < 12) {
-                            v = fac[O_WV + i];                 // P_{k+1} rb_k, left by the factorisation
-                        } else {
-                            // c_j: everything in p_k = c + Acl' p_{k+1} that does not depend on p_{k+1}
-                            const int j = i - 12;
-                            const double *w = fac + O_WV;
-                            v = gt[6 + j] + (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
+                        v = gt[6 + j] + (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
 #pragma unroll
-                            for (int m = 0; m < 6; m++) v -= fac[O_K + m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
-                        }
+                        for (int m = 0; m < 6; m++) v -= kf[m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
                     }
-                    vv[(size_t)s * WV + i] = v;
+                    vc[(size_t)s * WC + j] = v;
                 }
             });
             PROF_T0(ts);
+            ex.overlap([&]() {
             for (int k = k1; k >= k0; k--) {
                 const double *gt = vgr + (size_t)(k - k0) * WGR;
-                const double *wv = vv + (size_t)(k - k0) * WV;
-                double *fac = v4 + (size_t)(k - k0) * L4;
+                const double *cv = vc + (size_t)(k - k0) * WC;
+                const double *kf = vk + (size_t)(k - k0) * WK;
+                double *hp = ohp + (size_t)(k - k0) * WHP;
                 const int nxt = cur ^ 1;
                 if (k == Nl) {
                     ex.seq([&](int lane) {
                         if (lane < NX) {
                             const double v = gt[6 + lane];
                             pr.at(lane) = v; ex.share(sm.pv[cur], lane, v);
-                            fac[O_PV + lane] = v;
+                            hp[6 + lane] = v;
                         }
+                        if (lane < NU) hp[lane] = 0.0;
                     });
                     continue;
                 }
@@ -875,18 +900,32 @@ struct Engine {
                         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
                         for (int i = 0; i < 6; i += 2) {
-                            acc0 += fac[O_K + i * 12 + j] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
-                            acc1 += fac[O_K + (i + 1) * 12 + j] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
+                            acc0 += kf[i * 12 + j] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
+                            acc1 += kf[(i + 1) * 12 + j] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
                         }
                         const double at = j < 6 ? mine : c2.x * oq + c2.y * mine;
-                        const double pj = wv[12 + j] + (at - (acc0 + acc1));
+                        const double pj = cv[j] + (at - (acc0 + acc1));
                         pr.at(lane) = pj; ex.share(sm.pv[nxt], lane, pj);
-                        fac[O_PV + j] = pj;
+                        hp[6 + j] = pj;
                     }
                 });
                 cur = nxt;
             }
-            ex.join();
+            }, [&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                if (nk1 >= 0) {
+                    copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
+                    copy_lanes<42, 0, W3, L3, true, NL>(n3, c.w.G3, nk0, nk1, lane);
+                    copy_lanes<48, O_DLAM, W3, L3, true, NL>(n3 + C_DLAM, c.w.G3, nk0, nk1, lane);
+                    copy_lanes<WGR, O_GT, W2, WGR, true, NL>(ngr, c.w.G2, nk0, nk1, lane);
+                    copy_lanes<WK, O_K, W4, WK, true, NL>(nk, c.w.G4, nk0, nk1, lane);
+                    copy_lanes<WW, O_WV, W4, WW, true, NL>(nw, c.w.G4, nk0, nk1, lane);
+                }
+                if (k1 < Nl) {
+                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(prm, c.w.G3, k1 + 1, k1 + CH, lane);
+                    copy_lanes<WHP, O_HU, W4, WHP, false, NL>(php, c.w.G4, k1 + 1, k1 + CH, lane);
+                }
+            });
             PROF_ADD(PF_SEQ_BWD, ts);
             // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k)
             ex.par([&](int lane) {
@@ -894,14 +933,16 @@ struct Engine {
                 for (int e = lane; e < rows * 6; e += NT) {
                     const int s = e / 6, i = e - s * 6, k = k0 + s;
                     if (k >= Nl) continue;
-                    const double *gt = vgr + (size_t)s * WGR, *wv = vv + (size_t)s * WV;
-                    double *fac = v4 + (size_t)s * L4;
-                    const double *pn = fac + L4 + O_PV;
-                    fac[O_HU + i] = gt[i] + P.b1[i] * (pn[i] + wv[i]) + P.b2[i] * (pn[6 + i] + wv[6 + i]);
+                    const double *gt = vgr + (size_t)s * WGR, *w = vw + (size_t)s * WW;
+                    // p_{k+1}: next row of this chunk, or the lowest row of the previous chunk (other buffer)
+                    const double *pn = (s + 1 < rows ? ohp + (size_t)(s + 1) * WHP : php) + 6;
+                    ohp[(size_t)s * WHP + i] = gt[i] + P.b1[i] * (pn[i] + w[i]) + P.b2[i] * (pn[6 + i] + w[6 + i]);
                 }
             });
-            copy_rect<24, O_RM, W3, L3, false>(const_cast<double *>(v3 + O_RM), c.w.G3, k0, k1);
-            copy_rect<18, O_HU, W4, L4, false>(const_cast<double *>(v4 + O_HU), c.w.G4, k0, k1);
+            if (k0 == 0) {
+                copy_rect<WRM, O_RM, W3, WRM, false>(orm, c.w.G3, k0, k1);
+                copy_rect<WHP, O_HU, W4, WHP, false>(ohp, c.w.G4, k0, k1);
+            }
         }
         PROF_ADD(PF_BWD, t0);
     }
@@ -922,7 +963,8 @@ struct Engine {
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
         // K, R~^-1, h_u (no p, no P) and leaves only dlam, dt behind for the corrector
         constexpr int LF = AFFINE ? O_PV : W4;
-        const int CH = chunk_len(LF + WRB + WLT + WR + WO + WH, 0);
+        constexpr int PER = LF + WRB + WLT + WR + WO + WH;
+        const int CH = chunk_len(2 * PER, 0);   // two chunks in flight (see fact_pass)
         double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
         typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
         typename Ex::template PerLane<double> dxr;  // lanes < 12: dx_k[lane], carried from stage to stage
@@ -935,19 +977,27 @@ struct Engine {
             dxr.at(lane) = 0.0;                    // dx_0 = 0: x_0 is pinned by the init pass
             if (lane < NX) ex.share(sm.dx[0], lane, 0.0);
         });
-        int cur = 0;
-        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+        int cur = 0, bsel = 0;
+        {
+            double *q4 = ex.pool(), *qrb = q4 + (size_t)CH * LF, *qlt = qrb + (size_t)CH * WRB, *qr = qlt + (size_t)CH * WLT;
+            const int e1 = imin(CH - 1, Nl);
+            load_rect<LF, 0, W4>(q4, c.w.G4, 0, e1);
+            load_rect<WRB, O_RB, W2>(qrb, c.w.G2, 0, e1);
+            load_rect<WLT, O_QLAM, W1>(qlt, c.w.G1, 0, e1);
+            load_rect<WR, O_RD, W3>(qr, c.w.G3, 0, e1);
+        }
+        for (int k0 = 0; k0 <= Nl; k0 += CH, bsel ^= 1) {
             const int k1 = imin(k0 + CH - 1, Nl);
-            double *v4 = ex.pool();                   // rows k0..k1, G4
+            double *v4 = ex.pool() + (size_t)bsel * CH * PER;   // rows k0..k1, G4
             double *vrb = v4 + (size_t)CH * LF;       // RB
             double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
             double *vr = vlt + (size_t)CH * WLT;      // RD | RM
             double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
-            double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6)
-            load_rect<LF, 0, W4>(v4, c.w.G4, k0, k1);
-            load_rect<WRB, O_RB, W2>(vrb, c.w.G2, k0, k1);
-            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, k0, k1);
-            load_rect<WR, O_RD, W3>(vr, c.w.G3, k0, k1);
+            double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6) | e (12)
+            // the other buffer: inputs of the next chunk, output of the previous one
+            double *n4 = ex.pool() + (size_t)(bsel ^ 1) * CH * PER, *nrb = n4 + (size_t)CH * LF, *nlt = nrb + (size_t)CH * WRB,
+                   *nr = nlt + (size_t)CH * WLT, *po = nr + (size_t)CH * WR;
+            const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
             // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
             // does not depend on dx_k
             ex.par([&](int lane) {
@@ -965,6 +1015,7 @@ struct Engine {
                 }
             });
             PROF_T0(ts);
+            ex.overlap([&]() {
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
@@ -996,7 +1047,19 @@ struct Engine {
                 });
                 if (k < Nl) cur = nxt;
             }
-            ex.join();
+            }, [&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                if (nk0 <= Nl) {
+                    copy_lanes<LF, 0, W4, LF, true, NL>(n4, c.w.G4, nk0, nk1, lane);
+                    copy_lanes<WRB, O_RB, W2, WRB, true, NL>(nrb, c.w.G2, nk0, nk1, lane);
+                    copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
+                    copy_lanes<WR, O_RD, W3, WR, true, NL>(nr, c.w.G3, nk0, nk1, lane);
+                }
+                if (k0 > 0) {
+                    if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, c.w.G3, k0 - CH, k0 - 1, lane);
+                    else copy_lanes<WO, O_DW, W3, WO, false, NL>(po, c.w.G3, k0 - CH, k0 - 1, lane);
+                }
+            });
             PROF_ADD(PF_SEQ_FWD, ts);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -1060,8 +1123,10 @@ struct Engine {
             s0 += ex.get_sum(sm.red[1]);
             s1 += ex.get_sum(sm.red[2]);
             s2 += ex.get_sum(sm.red[3]);
-            if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
-            else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
+            if (k1 == Nl) {   // last chunk: nothing left to hide the store behind
+                if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
+                else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
+            }
         }
         S[0] = s0; S[1] = s1; S[2] = s2;
         PROF_ADD(PF_FWD, t0);

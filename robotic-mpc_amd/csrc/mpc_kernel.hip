@@ -5,6 +5,7 @@
 // fence + wave barrier: no s_barrier, no forced vmcnt(0) -- a single wave issues its LDS and
 // vector-memory instructions in order, which is all the bulk-synchronous phases need.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdio>
@@ -83,6 +84,24 @@ struct DevExec {
     __device__ __forceinline__ void join()
     {
         if (NWV > 1) __syncthreads();
+    }
+    // A stage-by-stage recursion (`fg`, made of seq phases, wavefront 0) with the other wavefronts
+    // doing barrier-free background work `bg(lane, lanes)` (chunk copies for the neighbouring
+    // chunks) in its shadow; ends with the workgroup barrier.  With one wavefront per simulation
+    // the two simply run one after the other.
+    template <class FG, class BG>
+    __device__ __forceinline__ void overlap(FG &&fg, BG &&bg)
+    {
+        if (NWV == 1) {
+            fg();
+            wave_fence();
+            bg(lane_id(), std::integral_constant<int, WAVE>{});
+            wave_fence();
+        } else {
+            if (threadIdx.x < WAVE) fg();
+            else bg(lane_id() - WAVE, std::integral_constant<int, WAVE *(NWV > 1 ? NWV - 1 : 1)>{});
+            __syncthreads();
+        }
     }
     // ---- values handed from lane to lane between consecutive seq phases (registers, no LDS) ----
     // share(): publish this lane's value for the next phase (a register stays a register here);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 
 #include "../../robotic-mpc_amd/csrc/mpc_core.h"
 #include "../../robotic-mpc_amd/csrc/mpc_pack.h"
@@ -44,6 +45,14 @@ struct HostExec {
         for (int l = 0; l < WAVE; l++) f(l);
     }
     void join() {}
+    template <class FG, class BG>
+    void overlap(FG &&fg, BG &&bg)
+    {
+        // no concurrency here: the background work must not depend on the recursion (or the
+        // other way round), so any order is valid; run it first to catch a forward dependency
+        for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
+        fg();
+    }
     // lane-to-lane hand-over between seq phases: through the (double-buffered) slot array here
     static void share(double *slot, int lane, double v) { slot[lane] = v; }
     static double gather(const double *slot, int j, double) { return slot[j]; }
