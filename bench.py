@@ -50,6 +50,20 @@ def bytes_per_mpc_step(N: int) -> int:
     return 8 * (108 * N + 95)
 
 
+def pmc_traffic(batch, N, Nsim, solver):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/r01_pmc_summary.json, written by scripts/profile_gpu.sh); None when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if (d.get("batch"), d.get("N"), d.get("Nsim"), d.get("solver")) == (batch, N, Nsim, solver):
+            return float(d["hbm_bytes_per_launch"]), "profiles/r01_pmc_summary.json (separate --pmc passes)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def cpu_baseline(cfgs, chain, budget_s: float = 20.0):
     """Oracle (plain-C port of the reference algorithm) on the host cores, bounded sample."""
     from oracle import orc
@@ -177,6 +191,8 @@ def main():
     # secondary: fp64 VALU estimate: ipm_iters*N*1e4 + n_lin*(N+1)*3e3 flop per MPC step
     flops_step = qp_iters * pb.N * 1.0e4 + 1.0 * (pb.N + 1) * 3.0e3
     info = eng.kernel_info()
+    geo = eng.launch_info()
+    traffic, traffic_src = pmc_traffic(args.batch, pb.N, pb.Nsim, args.solver)
 
     line = {
         "metric": "MPC-steps/sec (whole node), UR10 N=100 dt=0.01 batch; 1/2/4/8 GPU",
@@ -186,10 +202,10 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: batch={args.batch} UR10 sims per GPU, N={pb.N}, dt=0.01, "
                                f"{pb.Nsim} closed-loop steps, {args.solver}, flat surface, q_0 jitter U(-0.1,0.1) rng({rank})",
                    "batch_per_gpu": args.batch, "horizon": pb.N, "closed_loop_steps": pb.Nsim, "solver": args.solver,
-                   "parallelism": f"{world} x (1 wavefront per simulation)", "gather": gather_note,
+                   "parallelism": f"{world} GPU x {args.batch} workgroups (one simulation each) x {geo['waves_per_sim']} wavefronts", "gather": gather_note,
                    "mean_qp_iters_per_step": qp_iters, "solver_failures": failures},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mpc_rollout_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "latency / fp64-VALU bound by construction (sequential Riccati), see DESIGN.md",

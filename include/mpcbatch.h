@@ -125,6 +125,10 @@ int mpcb_last_kernel_ms(mpcb_handle *h, float *ms);
 /* Static resources of the rollout kernel: VGPRs, SGPRs(0 if unknown), LDS bytes, scratch bytes. */
 int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
 
+/* Launch geometry chosen by mpcb_setup for the current batch: wavefronts cooperating on one
+ * simulation (one workgroup per simulation), and the dynamic-LDS chunk pool per workgroup. */
+int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes);
+
 /* Convenience for callers without device buffers of their own: setup + rollout(0,Nsim) +
  * copy-back into HOST arrays `out_host`. */
 int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host,

@@ -418,6 +418,14 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
     return MPCB_OK;
 }
 
+int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes)
+{
+    if (!h || !h->ready) return MPCB_EINVAL;
+    if (waves_per_sim) *waves_per_sim = h->waves_per_sim;
+    if (pool_bytes) *pool_bytes = h->pool_doubles * (int)sizeof(double);
+    return MPCB_OK;
+}
+
 // Diagnostic builds only (-DMPCB_PROFILE): per-section device seconds accumulated by instance
 // `inst`; all zeros in the product build.  Not part of include/mpcbatch.h.
 int mpcb_debug_profile(mpcb_handle *h, int inst, double *out16)

@@ -49,7 +49,7 @@ class EngineError(RuntimeError):
 
 _EXPORTS = ("mpcb_version", "mpcb_device_count", "mpcb_create", "mpcb_destroy", "mpcb_last_error",
             "mpcb_workspace_bytes", "mpcb_result_bytes_per_sim", "mpcb_setup", "mpcb_rollout", "mpcb_sync",
-            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_run")
+            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_run")
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -134,6 +134,12 @@ class MpcBatchEngine:
         v = [C.c_int(0) for _ in range(4)]
         self._check(self.lib.mpcb_kernel_info(self._h, *[C.byref(x) for x in v]), "mpcb_kernel_info")
         return dict(vgprs=v[0].value, sgprs=v[1].value, lds_bytes=v[2].value, scratch_bytes=v[3].value)
+
+    def launch_info(self) -> Dict[str, int]:
+        """Launch geometry chosen by setup(): wavefronts per simulation, LDS chunk pool bytes."""
+        w, pbytes = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mpcb_launch_info(self._h, C.byref(w), C.byref(pbytes)), "mpcb_launch_info")
+        return dict(waves_per_sim=w.value, pool_bytes=pbytes.value)
 
     # ------------------------------------------------------------------ device-resident path
     def setup(self, cfgs: Sequence[Dict], chain) -> MpcbProblem:

@@ -7,6 +7,7 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline"
+rm -rf $OUT/kt $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py $ARGS > $OUT/bench_kt.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1 || exit 2
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/bench_write.log 2>&1 || exit 3
@@ -23,6 +24,18 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
                 continue
             summary.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 res = {k: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for k, v in summary.items()}
+# workload of the profiled command (bench.py defaults) -- bench.py matches on these before quoting the traffic
+res.update({"batch": 256, "N": 100, "Nsim": 600, "solver": "SQP_RTI"})
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    # MI355X_MICROARCH.md (HBM): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests
+    # of wide (16 B/lane) streaming reads at 64 B -> double it; WRITE_SIZE is exact for 16 B/lane stores
+    res["hbm_bytes_per_launch"] = (2.0 * res["FETCH_SIZE"]["per_launch_mean"] + res["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+    res["correction"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes"
+# kernel-trace average of the same command
+for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "mpc_rollout_kernel" in row.get("Name", ""):
+            res["kernel_trace"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "name": row["Name"][:60]}
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res))
 PY
