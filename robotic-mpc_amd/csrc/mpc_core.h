@@ -44,7 +44,7 @@ constexpr double BOUND_INF = 1e29;
 #define PROF_T0(v)
 #define PROF_ADD(i, v)
 #endif
-enum { PF_NLP = 0, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_MERIT, PF_PLANT, PF_TOTAL, PF_COUNT_IPM, PF_IO, PF_SEQ_FACT, PF_SEQ_BWD, PF_SEQ_FWD };
+enum { PF_NLP = 0, PF_RES, PF_FACT, PF_BWD, PF_FWD, PF_MERIT, PF_PLANT, PF_TOTAL, PF_COUNT_IPM, PF_IO, PF_SEQ_FACT, PF_SEQ_BWD, PF_SEQ_FWD, PF_X1, PF_X2, PF_X3 };
 
 // The LDS working set is reached through the executor (ex.smem(), ex.pool()) and never through a
 // stored pointer: inside a non-inlined pass a pointer loaded from `this` is a generic (flat)
@@ -78,7 +78,7 @@ MPC_HD double bnd_hi(const InstParams &P, int j) { return j < 6 ? P.umax[j] : P.
 MPC_HD int imin(int a, int b) { return a < b ? a : b; }
 MPC_HD int imax(int a, int b) { return a > b ? a : b; }
 
-// 1/d for the LDL' pivots: hardware reciprocal seed (measured 4.6e-8 relative on gfx950,
+// 1/d for the LDL' pivots and the slack divisions of the interior-point formulas: hardware reciprocal seed (measured 4.6e-8 relative on gfx950,
 // scripts/microbench/rcptest.hip) + one third-order correction x (1 + e + e^2), e = 1 - d x:
 // three dependent FMAs to full fp64 accuracy instead of the ~40-instruction IEEE division on the
 // sequential critical path.
@@ -417,6 +417,7 @@ struct Engine {
             load_rect<W1, 0, W1>(v1, c.w.G1, lo, hi);
             if (mode == 1) load_rect<W3D, O_DW, W3>(v3d, c.w.G3, lo, hi);
             load_rect<W2_LIN, 0, W2>(v2, c.w.G2, k0, k1);
+            PROF_T0(tx);
             ex.par([&](int lane) {
                 const int rows = hi - lo + 1;
                 double ncl = 0.0;
@@ -491,27 +492,27 @@ struct Engine {
                         const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
                         const double v = hc ? r1[ci < 6 ? O_U + ci : O_X + ci - 6] : 0.0, dv = r1[O_QW + ci];
                         double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                        gt = rg;
                         if (blo) {
-                            const double l = r1[O_QLAM + ci], t = r1[O_QT + ci];
+                            const double l = r1[O_QLAM + ci], t = r1[O_QT + ci], it = fast_rcp(t);
                             rdl = dv - (bnd_lo(P, ci) - v) - t;
                             rml = l * t;
-                            rg -= l;
-                            gam += l / t;
+                            rg -= l; gt -= l;
+                            gam += l * it;
+                            gt += (rml + l * rdl) * it;
                             a_mu += rml;
                             a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
                         }
                         if (bhi) {
-                            const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci];
+                            const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci], it = fast_rcp(t);
                             rdu = (bnd_hi(P, ci) - v) - dv - t;
                             rmu = l * t;
-                            rg += l;
-                            gam += l / t;
+                            rg += l; gt += l;
+                            gam += l * it;
+                            gt -= (rmu + l * rdu) * it;
                             a_mu += rmu;
                             a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
                         }
-                        gt = rg;
-                        if (blo) gt += (rml + r1[O_QLAM + ci] * rdl) / r1[O_QT + ci];
-                        if (bhi) gt -= (rmu + r1[O_QLAM + 12 + ci] * rdu) / r1[O_QT + 12 + ci];
                         o3[O_RD + ci] = rdl; o3[O_RD + 12 + ci] = rdu;
                         o3[O_RM + ci] = rml; o3[O_RM + 12 + ci] = rmu;
                         og[ci] = gam;
@@ -540,6 +541,7 @@ struct Engine {
             nd = fmax(nd, ex.get_max(sm.red[2]));
             nm = fmax(nm, ex.get_max(sm.red[3]));
             smu += ex.get_sum(sm.red[4]);
+            PROF_ADD(PF_X1, tx);
             copy_rect<78, O_QW, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1 + O_QW), c.w.G1, k0, k1);
             copy_rect<10, 0, W2, W2_LIN, false>(const_cast<double *>(v2), c.w.G2, k0, k1);        // r (unchanged) and y
             copy_rect<WG, O_GAM, W2, WG, false>(const_cast<double *>(vg), c.w.G2, k0, k1);        // Gamma | gt | rb
@@ -844,12 +846,12 @@ struct Engine {
                         if (bnd_lo(P, j) > -BOUND_INF) {
                             const double l = lt[j], t = lt[24 + j];
                             rml = l * t + r3[C_DLAM + j] * r3[C_DT + j] - sigma_mu;
-                            gt += (rml + l * r3[18 + j]) / t;
+                            gt += (rml + l * r3[18 + j]) * fast_rcp(t);
                         }
                         if (bnd_hi(P, j) < BOUND_INF) {
                             const double l = lt[12 + j], t = lt[36 + j];
                             rmu = l * t + r3[C_DLAM + 12 + j] * r3[C_DT + 12 + j] - sigma_mu;
-                            gt -= (rmu + l * r3[18 + 12 + j]) / t;
+                            gt -= (rmu + l * r3[18 + 12 + j]) * fast_rcp(t);
                         }
                         vgr[(size_t)s * WGR + j] = gt;
                     }
@@ -1003,6 +1005,7 @@ struct Engine {
             const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
             // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
             // does not depend on dx_k
+            PROF_T0(tx2);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 6; e += NT) {
@@ -1017,6 +1020,7 @@ struct Engine {
                     h[12 + i] = vrb[(size_t)s * WRB + 6 + i] - P.b2[i] * v;
                 }
             });
+            PROF_ADD(PF_X2, tx2);
             PROF_T0(ts);
             ex.overlap([&]() {
             for (int k = k0; k <= k1; k++) {
@@ -1064,6 +1068,7 @@ struct Engine {
                 }
             });
             PROF_ADD(PF_SEQ_FWD, ts);
+            PROF_T0(tx3);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 18; e += NT) {
@@ -1104,17 +1109,17 @@ struct Engine {
                     if (hc && bnd_lo(P, j) > -BOUND_INF) {
                         const double l = lt[j], t = lt[24 + j];
                         dtl = dv + r[j];
-                        dll = -(r[24 + j] + l * dtl) / t;
-                        if (dll < 0 && l + al * dll < 0) al = -l / dll;
-                        if (dtl < 0 && t + al * dtl < 0) al = -t / dtl;
+                        dll = -(r[24 + j] + l * dtl) * fast_rcp(t);
+                        if (dll < 0 && l + al * dll < 0) al = -l * fast_rcp(dll);
+                        if (dtl < 0 && t + al * dtl < 0) al = -t * fast_rcp(dtl);
                         a0 += l * t; a1 += l * dtl + t * dll; a2 += dll * dtl;
                     }
                     if (hc && bnd_hi(P, j) < BOUND_INF) {
                         const double l = lt[12 + j], t = lt[36 + j];
                         dtu = -dv + r[12 + j];
-                        dlu = -(r[36 + j] + l * dtu) / t;
-                        if (dlu < 0 && l + al * dlu < 0) al = -l / dlu;
-                        if (dtu < 0 && t + al * dtu < 0) al = -t / dtu;
+                        dlu = -(r[36 + j] + l * dtu) * fast_rcp(t);
+                        if (dlu < 0 && l + al * dlu < 0) al = -l * fast_rcp(dlu);
+                        if (dtu < 0 && t + al * dtu < 0) al = -t * fast_rcp(dtu);
                         a0 += l * t; a1 += l * dtu + t * dlu; a2 += dlu * dtu;
                     }
                     o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
@@ -1126,6 +1131,7 @@ struct Engine {
             s0 += ex.get_sum(sm.red[1]);
             s1 += ex.get_sum(sm.red[2]);
             s2 += ex.get_sum(sm.red[3]);
+            PROF_ADD(PF_X3, tx3);
             if (k1 == Nl) {   // last chunk: nothing left to hide the store behind
                 if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
                 else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);

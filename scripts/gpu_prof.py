@@ -22,7 +22,7 @@ for i in range(B):
 pb, bufs = eng.run_device(cf, ch)
 ms = sum(eng.last_kernel_ms)
 print(f"B={B} N={N} Nsim={pb.Nsim}: kernel {ms:.1f} ms -> {B*pb.Nsim/(ms*1e-3):.0f} steps/s, per step {ms/pb.Nsim*1e3:.1f} us")
-names = ["nlp", "res", "fact", "bwd", "fwd", "merit", "plant", "total", "ipm_iters", "io", "seq_fact", "seq_bwd", "seq_fwd", "-", "-", "-"]
+names = ["nlp", "res", "fact", "bwd", "fwd", "merit", "plant", "total", "ipm_iters", "io", "seq_fact", "seq_bwd", "seq_fwd", "x1", "x2", "x3"]
 out = (C.c_double * 16)()
 eng.lib.mpcb_debug_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
 for inst in (0, B // 2):
@@ -30,5 +30,5 @@ for inst in (0, B // 2):
     v = np.array(out[:])
     its = v[8]
     print(f"inst {inst}: ipm iters {its:.0f} ({its/pb.Nsim:.2f}/step)")
-    for n, x in zip(names[:13], v[:13]):
+    for n, x in zip(names[:16], v[:16]):
         print(f"   {n:6s} {x*1e3:9.2f} ms  {x/pb.Nsim*1e6:8.1f} us/step  {100*x/max(v[7]+v[6],1e-12):5.1f}%")
