@@ -1,6 +1,7 @@
 """The C-ABI library builds for gfx950 here (no GPU), loads, exports every symbol that
 include/mpcbatch.h declares, and refuses loudly to run without a device."""
 import ctypes as C
+import sys
 import os
 import re
 
@@ -90,3 +91,27 @@ def test_param_packing_layout():
     np.testing.assert_array_equal(p[38:44], cfg["umin"])
     np.testing.assert_array_equal(p[50:56], [-0.15, 0.15, -0.01, 0.01, 0.01, 0.0])
     np.testing.assert_array_equal(p[56:61], [50.0] * 5)
+
+
+def test_asm_scanner_detects_empty_exec_reload():
+    """scripts/check_asm.py: the pattern of the hipcc 7.2 miscompile is recognised."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_asm", os.path.join(ROOT, "scripts", "check_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = "\n".join(["_Z3foov:", ".LBB0_1:", "\ts_andn2_b64 exec, exec, s[8:9]", "\ts_cbranch_execnz .LBB0_1",
+                     "\tv_accvgpr_read_b32 v61, a11", "\ts_barrier", "\ts_branch .LBB0_2"])
+    good = "\n".join(["_Z3foov:", ".LBB0_1:", "\ts_andn2_b64 exec, exec, s[8:9]", "\ts_cbranch_execnz .LBB0_1",
+                      "\ts_or_b64 exec, exec, s[8:9]", "\tv_accvgpr_read_b32 v61, a11"])
+    assert len(mod.scan(bad)) == 1 and mod.scan(bad)[0][0] == "_Z3foov"
+    assert mod.scan(good) == []
+
+
+def test_generated_isa_has_no_vector_op_under_empty_exec():
+    """The shipped kernel source compiles (gfx950) without the miscompile pattern."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_asm.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
