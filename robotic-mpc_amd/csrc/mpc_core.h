@@ -579,7 +579,7 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
-        const int CH = chunk_len(2 * (WR + W4), 2 * WR);
+        const int CH = chunk_len(3 * WR + 2 * W4, 3 * WR);
         typename Ex::template PerLane<FactLane> fl;
         ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
@@ -611,33 +611,121 @@ struct Engine {
             f.qvv = cq * f.a12b + cv * f.a22b;
             (void)lane;
         };
-        // Two chunks in flight: while wavefront 0 runs the recursion on chunk c, the other wavefronts
-        // fetch the inputs of chunk c+1 and write the factor of chunk c-1 back (Ex::overlap).
-        int cur = 0, sb = 0, bsel = 0;
-        const size_t buf = (size_t)(CH + 1) * WR + (size_t)CH * W4;
-        load_rect<WR, O_GQ, W2>(ex.pool(), c.w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
-        for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
+        // Three roles per window (Ex::overlap3), chunk index ci counts down the horizon:
+        //   wavefront 0   matrix recursion (P, K, R~^-1) of chunk ci
+        //   wavefront 1   vector recursion (w, h_u, p) of chunk ci-1 on the finished matrices, then
+        //                 writes those columns back
+        //   wavefronts 2+ fetch the inputs of chunk ci+1, write the matrix columns of chunk ci-1 back
+        // Inputs are triple-buffered (chunk ci-1 is still read while ci+1 arrives), the factor is
+        // double-buffered; the lowest-stage P of every chunk is kept in sm.Pseam[ci % 3] because the
+        // factor buffer of chunk ci-2 is being overwritten when the vector recursion of ci-1 needs it.
+        int sb = 0;
+        double *const vr_base = ex.pool();
+        double *const vf_base = vr_base + 3 * (size_t)(CH + 1) * WR;
+        auto vr_of = [&](int ci) { return vr_base + (size_t)(ci % 3) * (CH + 1) * WR; };
+        auto vf_of = [&](int ci) { return vf_base + (size_t)(ci & 1) * CH * W4; };
+        auto k1_of = [&](int ci) { return Nl - ci * CH; };
+        typename Ex::template PerLane<double> pr;   // wavefront 1, lanes < 12: p_{k+1}[lane]
+        typename Ex::template PerLane<double> tr, wr;
+        typename Ex::template PerLane<D2> ab;       // wavefront 1, lanes < 12: (a12, a22) of the lane's joint
+        double b1r[6], b2r[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { b1r[i] = P.b1[i]; b2r[i] = P.b2[i]; }
+        int vcur = 0;
+        // vector recursion of chunk ci (stages k1c..k0c) -- runs on ONE wavefront (Ex::sub phases)
+        auto vec_sweep = [&](int ci) {
+            const int k1c = k1_of(ci), k0c = imax(k1c - CH + 1, 0), klc = imax(k0c - 1, 0);
+            const double *vr = vr_of(ci);
+            double *vf = vf_of(ci);
+            for (int k = k1c; k >= k0c; k--) {
+                const double *ric = vr + (size_t)(k - klc) * WR;
+                const double *gt = ric + 48, *rbv = ric + 66;
+                double *fac = vf + (size_t)(k - k0c) * W4;
+                // P_{k+1}: next row of this chunk, or the seam copy left by the chunk above
+                const double *Pn = k < k1c ? fac + W4 + O_PM : sm.Pseam[(ci + 2) % 3];
+                const int vnxt = vcur ^ 1;
+                if (k == Nl) {
+                    ex.sub([&](int lane) {
+                        if (lane < NX) {
+                            const double v = gt[6 + lane];
+                            pr.at(lane) = v; ex.share(sm.pv[vcur], lane, v);
+                            fac[O_PV + lane] = v; fac[O_WV + lane] = 0.0;
+                            const int j = lane % 6;
+                            D2 c2; c2.x = P.a12[j]; c2.y = P.a22[j];
+                            ab.at(lane) = c2;
+                        }
+                        if (lane < NU) fac[O_HU + lane] = 0.0;
+                    });
+                    continue;
+                }
+                ex.sub([&](int lane) {
+                    // t = p_{k+1} + P_{k+1} rb_k (lane i < 12 owns component i)
+                    double t = 0.0, w = 0.0;
+                    if (lane < NX) {
+                        const double *Mn = Pn + lane * 12;
+                        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NX; j += 2) { w0 += Mn[j] * rbv[j]; w1 += Mn[j + 1] * rbv[j + 1]; }
+                        w = w0 + w1;
+                        t = pr.at(lane) + w;
+                    }
+                    tr.at(lane) = t; wr.at(lane) = w;
+                    ex.share(sm.mt2[vcur], lane < NX ? lane : NX, t);
+                });
+                ex.sub([&](int lane) {
+                    const double t = tr.at(lane), w = wr.at(lane);
+                    double tv[12];
+#pragma unroll
+                    for (int i = 0; i < NX; i++) tv[i] = ex.gather(sm.mt2[vcur], i, t);
+                    const double oq = ex.shr6(sm.mt2[vcur], lane, t);      // lanes 6..11: t[lane - 6]
+                    if (lane < NX) {
+                        const int j = lane;
+                        double hu[6];
+#pragma unroll
+                        for (int m = 0; m < 6; m++) hu[m] = gt[m] + b1r[m] * tv[m] + b2r[m] * tv[6 + m];
+                        const D2 c2 = ab.at(lane);
+                        double pj = gt[6 + j] + (j < 6 ? t : c2.x * oq + c2.y * t);
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 6; m += 2) { s0 += fac[O_K + m * 12 + j] * hu[m]; s1 += fac[O_K + (m + 1) * 12 + j] * hu[m + 1]; }
+                        pj -= s0 + s1;
+                        pr.at(lane) = pj; ex.share(sm.pv[vnxt], lane, pj);
+                        fac[O_PV + j] = pj;
+                        fac[O_WV + j] = w;
+                        if (j < 6) {
+                            double v = hu[0];
+#pragma unroll
+                            for (int m = 1; m < 6; m++) v = j == m ? hu[m] : v;
+                            fac[O_HU + j] = v;
+                        }
+                    }
+                });
+                vcur = vnxt;
+            }
+        };
+        load_rect<WR, O_GQ, W2>(vr_of(0), c.w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
+        int ci = 0;
+        for (int k1 = Nl; k1 >= -CH; k1 -= CH, ci++) {
+            // window ci: matrix recursion of chunk ci (none in the last window, which only drains)
+            const bool has_mat = k1 >= 0;
             const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
-            double *vr = ex.pool() + (size_t)bsel * buf; // rows kl..k1 (one halo row below: Gamma of stage k0-1)
-            double *vf = vr + (size_t)(CH + 1) * WR;     // rows k0..k1, W4
-            double *vr_n = ex.pool() + (size_t)(bsel ^ 1) * buf, *vf_p = vr_n + (size_t)(CH + 1) * WR;
-            const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);
+            double *vr = vr_of(ci), *vf = vf_of(ci);
+            const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);   // chunk ci+1
+            const int pk1 = k1 + CH, pk0 = imax(pk1 - CH + 1, 0);                            // chunk ci-1
+            if (!has_mat && ci == 0) break;
             PROF_T0(ts);
-            ex.overlap([&]() {
+            ex.overlap3([&]() {
+            if (has_mat)
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
                 double *fac = vf + (size_t)(k - k0) * W4;
-                const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
-                const int nxt = cur ^ 1;
+                const double *gam = ric + 36;
                 if (k == Nl) {
-                    // terminal stage: no cost, no bounds -> P_N = 0, p_N = gt_N,x ; R~, S~ of stage N-1
+                    // terminal stage: no cost, no bounds -> P_N = 0 ; R~, S~ of stage N-1
                     ex.seq([&](int lane) {
-                        for (int e = lane; e < 144; e += WAVE) { fac[O_PM + e] = 0.0; sm.M[cur][e] = 0.0; }
-                        if (lane >= 40 && lane < 40 + NX) {
-                            sm.pv[cur][lane - 40] = gt[6 + lane - 40]; fac[O_PV + lane - 40] = gt[6 + lane - 40];
-                            fac[O_WV + lane - 40] = 0.0;
-                        }
+                        for (int e = lane; e < 144; e += WAVE) fac[O_PM + e] = 0.0;
+                        if (k == k0) for (int e = lane; e < 144; e += WAVE) sm.Pseam[ci % 3][e] = 0.0;
                         if (lane < 36) {
                             FactLane &f = fl.at(lane);
                             f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
@@ -646,7 +734,7 @@ struct Engine {
                     });
                     continue;
                 }
-                // ---- B: LDL' (right-looking) + one right-hand side per lane; m~
+                // ---- B: LDL' (right-looking) + one right-hand side per lane
                 ex.seq([&](int lane) {
                     const double *St = sm.St2[sb];
                     double A_[6][6];
@@ -694,17 +782,9 @@ struct Engine {
 #pragma unroll
                             for (int i = 0; i < 6; i++) fac[O_RI + i * 6 + (lane - 12)] = x[i];
                         }
-                    } else if (lane >= 40 && lane < 40 + NX) {
-                        const int i = lane - 40;
-                        const double *Mn = sm.M[cur] + i * 12;         // row i of P_{k+1}
-                        double s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NX; j++) s += Mn[j] * rbv[j];
-                        fac[O_WV + i] = s;                             // w_k = P_{k+1} rb_k
-                        sm.mt[i] = sm.pv[cur][i] + s;
                     }
                 });
-                // ---- CA: P_k block, then R~/S~ of stage k-1 ; h_u and p_k
+                // ---- CA: P_k block, then R~/S~ of stage k-1
                 ex.seq([&](int lane) {
                     if (lane < 36) {
                         FactLane &f = fl.at(lane);
@@ -735,42 +815,36 @@ struct Engine {
                             fac[O_PM + f.a * 12 + 6 + f.b] = pqv;
                             fac[O_PM + (6 + f.a) * 12 + f.b] = pvq;
                             fac[O_PM + (6 + f.a) * 12 + 6 + f.b] = pvv;
-                            double *Mo = sm.M[nxt];                        // for m~ of stage k-1 (also across chunk seams)
-                            Mo[f.a * 12 + f.b] = pqq; Mo[f.a * 12 + 6 + f.b] = pqv;
-                            Mo[(6 + f.a) * 12 + f.b] = pvq; Mo[(6 + f.a) * 12 + 6 + f.b] = pvv;
+                            if (k == k0) {                                 // lowest stage of the chunk: seam copy
+                                double *Mo = sm.Pseam[ci % 3];
+                                Mo[f.a * 12 + f.b] = pqq; Mo[f.a * 12 + 6 + f.b] = pqv;
+                                Mo[(6 + f.a) * 12 + f.b] = pvq; Mo[(6 + f.a) * 12 + 6 + f.b] = pvv;
+                            }
                             next_stage(lane, f, ricd + 36, sb ^ 1);
-                        }
-                    } else if (lane >= 40 && lane < 40 + NX) {
-                        const int j = lane - 40;
-                        double hu[6];
-#pragma unroll
-                        for (int i = 0; i < 6; i++) hu[i] = gt[i] + P.b1[i] * sm.mt[i] + P.b2[i] * sm.mt[6 + i];
-                        double hx = gt[6 + j];
-                        if (j < 6) hx += sm.mt[j];
-                        else hx += P.a12[j - 6] * sm.mt[j - 6] + P.a22[j - 6] * sm.mt[j];
-                        double pj = hx;
-#pragma unroll
-                        for (int m = 0; m < 6; m++) pj -= sm.Kf[m * 12 + j] * hu[m];
-                        sm.pv[nxt][j] = pj;
-                        fac[O_PV + j] = pj;
-                        if (j < 6) {
-                            double v = hu[0];
-#pragma unroll
-                            for (int i = 1; i < 6; i++) v = j == i ? hu[i] : v;
-                            fac[O_HU + j] = v;
                         }
                     }
                 });
-                cur = nxt;
                 sb ^= 1;
             }
+            }, [&]() {
+                // wavefront 1: vector recursion of the previous chunk, then its h_u | p | w columns go home
+                if (ci > 0) {
+                    vec_sweep(ci - 1);
+                    ex.sub([&](int lane) {
+                        copy_lanes<30, O_HU, W4, W4, false, WAVE>(vf_of(ci - 1) + O_HU, c.w.G4, pk0, pk1, lane);
+                    });
+                }
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_n, c.w.G2, nkl, nk1, lane);
-                if (k1 < Nl) copy_lanes<W4, 0, W4, W4, false, NL>(vf_p, c.w.G4, k1 + 1, k1 + CH, lane);
+                if (has_mat && nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), c.w.G2, nkl, nk1, lane);
+                if (ci > 0) {
+                    copy_lanes<O_HU, 0, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
+                    copy_lanes<72, O_PM, W4, W4, false, NL>(vf_of(ci - 1) + O_PM, c.w.G4, pk0, pk1, lane);
+                    copy_lanes<72, O_PM + 72, W4, W4, false, NL>(vf_of(ci - 1) + O_PM + 72, c.w.G4, pk0, pk1, lane);
+                }
             });
             PROF_ADD(PF_SEQ_FACT, ts);
-            if (k0 == 0) store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);
+            if (!has_mat) break;
         }
         PROF_ADD(PF_FACT, t0);
     }

@@ -103,6 +103,35 @@ struct DevExec {
             __syncthreads();
         }
     }
+    // Three concurrent roles: wavefront 0 runs `fg` (seq phases), wavefront 1 runs `mid` (sub
+    // phases, wave-local), the remaining wavefronts run the barrier-free `bg(lane, lanes)`.
+    // With fewer wavefronts the roles run one after the other on the last wavefront.
+    template <class FG, class MID, class BG>
+    __device__ __forceinline__ void overlap3(FG &&fg, MID &&mid, BG &&bg)
+    {
+        if (NWV == 1) {
+            fg(); wave_fence();
+            mid(); wave_fence();
+            bg(lane_id(), std::integral_constant<int, WAVE>{});
+            wave_fence();
+        } else if (NWV == 2) {
+            if (threadIdx.x < WAVE) fg();
+            else { mid(); wave_fence(); bg(lane_id() - WAVE, std::integral_constant<int, WAVE>{}); }
+            __syncthreads();
+        } else {
+            if (threadIdx.x < WAVE) fg();
+            else if (threadIdx.x < 2 * WAVE) mid();
+            else bg(lane_id() - 2 * WAVE, std::integral_constant<int, WAVE *(NWV > 2 ? NWV - 2 : 1)>{});
+            __syncthreads();
+        }
+    }
+    // one step of a recursion that runs on a single wavefront inside overlap3's `mid`
+    template <class F>
+    __device__ __forceinline__ void sub(F &&f)
+    {
+        f(lane_id() & (WAVE - 1));
+        wave_fence();
+    }
     // ---- values handed from lane to lane between consecutive seq phases (registers, no LDS) ----
     // share(): publish this lane's value for the next phase (a register stays a register here);
     // gather(j): the value lane j published; shl6 / shr6: the value of lane + 6 / lane - 6

@@ -148,7 +148,8 @@ MPC_HD Ws ws_carve(double *base, int N)
 struct Smem {
     InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
     Robot rb;
-    double M[2][144];   // P_{k+1} / P_k double buffer during the factorisation sweep
+    double Pseam[3][144];  // lowest-stage P of the last three chunks of the factorisation sweep
+    double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)
     double pv[2][12];
     double Rt[36];      // R~ = H_uu + Gamma_u + B'MB
     double St[72];      // S~ = H_ux + B'MA           (6x12)

@@ -53,6 +53,18 @@ struct HostExec {
         for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
         fg();
     }
+    template <class FG, class MID, class BG>
+    void overlap3(FG &&fg, MID &&mid, BG &&bg)
+    {
+        for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
+        mid();
+        fg();
+    }
+    template <class F>
+    void sub(F &&f)
+    {
+        for (int l = 0; l < WAVE; l++) f(l);
+    }
     // lane-to-lane hand-over between seq phases: through the (double-buffered) slot array here
     static void share(double *slot, int lane, double v) { slot[lane] = v; }
     static double gather(const double *slot, int j, double) { return slot[j]; }
