@@ -1042,39 +1042,51 @@ struct Engine {
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
         // K, R~^-1, h_u (no p, no P) and leaves only dlam, dt behind for the corrector
         constexpr int LF = AFFINE ? O_PV : W4;
+        // Three roles per window ci (Ex::overlap3), two chunks in flight:
+        //   wavefront 0   state recursion dx of chunk ci; publishes its progress (sm.prog)
+        //   wavefront 1   follows it in blocks of BLK stages: du, dpi, dlam, dt, step length, centering sums
+        //   wavefronts 2+ fetch the inputs of chunk ci+1, write the step of chunk ci-1 back
         constexpr int PER = LF + WRB + WLT + WR + WO + WH;
-        const int CH = chunk_len(2 * PER, 0);   // two chunks in flight (see fact_pass)
-        double alpha = 1.0, s0 = 0, s1 = 0, s2 = 0;
+#ifndef MPCB_FWD_BLK
+#define MPCB_FWD_BLK 4
+#endif
+        constexpr int BLK = MPCB_FWD_BLK;          // stages per follower block: BLK x 12 bounded components <= 64 lanes
+        const int CH = chunk_len(2 * PER, 0);
+        const int NCH = (Nl + CH) / CH;            // number of chunks
+        double *const pool = ex.pool();
         typename Ex::template PerLane<D2> ab, bb;   // lanes < 12: (a12, a22), (b1, b2) of the lane's joint
         typename Ex::template PerLane<double> dxr;  // lanes < 12: dx_k[lane], carried from stage to stage
-        ex.seq([&](int lane) {
-            const int j = lane % 6;
+        typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;   // wavefront 1: running min / sums
+        ex.par([&](int lane) {
+            const int j = (lane & (WAVE - 1)) % 6;
             D2 v; v.x = P.a12[j]; v.y = P.a22[j];
             ab.at(lane) = v;
             D2 u; u.x = P.b1[j]; u.y = P.b2[j];
             bb.at(lane) = u;
             dxr.at(lane) = 0.0;                    // dx_0 = 0: x_0 is pinned by the init pass
             if (lane < NX) ex.share(sm.dx[0], lane, 0.0);
+            r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0;
+            if (lane == 0) ex.post(&sm.prog, -1);
         });
-        int cur = 0, bsel = 0;
+        int cur = 0;
         {
-            double *q4 = ex.pool(), *qrb = q4 + (size_t)CH * LF, *qlt = qrb + (size_t)CH * WRB, *qr = qlt + (size_t)CH * WLT;
+            double *q4 = pool, *qrb = q4 + (size_t)CH * LF, *qlt = qrb + (size_t)CH * WRB, *qr = qlt + (size_t)CH * WLT;
             const int e1 = imin(CH - 1, Nl);
             load_rect<LF, 0, W4>(q4, c.w.G4, 0, e1);
             load_rect<WRB, O_RB, W2>(qrb, c.w.G2, 0, e1);
             load_rect<WLT, O_QLAM, W1>(qlt, c.w.G1, 0, e1);
             load_rect<WR, O_RD, W3>(qr, c.w.G3, 0, e1);
         }
-        for (int k0 = 0; k0 <= Nl; k0 += CH, bsel ^= 1) {
-            const int k1 = imin(k0 + CH - 1, Nl);
-            double *v4 = ex.pool() + (size_t)bsel * CH * PER;   // rows k0..k1, G4
+        for (int ci = 0; ci < NCH; ci++) {
+            const int k0 = ci * CH, k1 = imin(k0 + CH - 1, Nl);
+            double *v4 = pool + (size_t)(ci & 1) * CH * PER;   // rows k0..k1, G4
             double *vrb = v4 + (size_t)CH * LF;       // RB
             double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
             double *vr = vlt + (size_t)CH * WLT;      // RD | RM
             double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
             double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6) | e (12)
             // the other buffer: inputs of the next chunk, output of the previous one
-            double *n4 = ex.pool() + (size_t)(bsel ^ 1) * CH * PER, *nrb = n4 + (size_t)CH * LF, *nlt = nrb + (size_t)CH * WRB,
+            double *n4 = pool + (size_t)((ci + 1) & 1) * CH * PER, *nrb = n4 + (size_t)CH * LF, *nlt = nrb + (size_t)CH * WRB,
                    *nr = nlt + (size_t)CH * WLT, *po = nr + (size_t)CH * WR;
             const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
             // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
@@ -1096,10 +1108,12 @@ struct Engine {
             });
             PROF_ADD(PF_X2, tx2);
             PROF_T0(ts);
-            ex.overlap([&]() {
+            ex.overlap3([&]() {
+            PROF_T0(tx3);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
+                const double *h = vh + (size_t)(k - k0) * WH;
                 double *o = vo + (size_t)(k - k0) * WO;
                 // dx_{k+1} = e_k + A dx_k - B K dx_k: dx_k travels lane to lane in registers
                 ex.seq([&](int lane) {
@@ -1120,14 +1134,73 @@ struct Engine {
                             }
                             const double kd = s0 + s1;
                             const D2 a = ab.at(lane), b = bb.at(lane);
-                            const double v = vh[(size_t)(k - k0) * WH + 6 + lane] +
-                                             (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                            const double v = h[6 + lane] + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
                             dxr.at(lane) = v; ex.share(sm.dx[nxt], lane, v);
                         }
                     }
+                    if (lane == 0) ex.post(&sm.prog, k);   // dx_k is in LDS (an unconditional post is cheaper than a modulo)
                 });
                 if (k < Nl) cur = nxt;
             }
+            PROF_ADD(PF_X3, tx3);
+            }, [&]() {
+                // wavefront 1 follows the recursion block by block: du_k = -(R~^-1 h_u + K dx_k), then
+                // dlam, dt (HPIPM compute_lam_t), largest feasible step, centering sums -- one phase,
+                // lane <-> (stage of the block, bounded component j): j < 6 input, j >= 6 joint position
+                for (int kb = k0; kb <= k1; kb += BLK) {
+                    const int ke = imin(kb + BLK - 1, k1), rows = ke - kb + 1;
+                    ex.await(&sm.prog, ke);
+                    ex.sub([&](int lane) {
+                        double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
+                        if (lane < rows * NB) {
+                            const int s = lane / NB, j = lane - s * NB, k = kb + s;
+                            const double *fac = v4 + (size_t)(k - k0) * LF;
+                            const double *lt = vlt + (size_t)(k - k0) * WLT, *r = vr + (size_t)(k - k0) * WR;
+                            double *o = vo + (size_t)(k - k0) * WO;
+                            const double *dxk = o + 6;
+                            double dv;
+                            if (j < 6) {
+                                dv = 0.0;
+                                if (k < Nl) {
+                                    double s0 = vh[(size_t)(k - k0) * WH + j], s1 = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < NX; i += 2) { s0 += fac[O_K + j * 12 + i] * dxk[i]; s1 += fac[O_K + j * 12 + i + 1] * dxk[i + 1]; }
+                                    dv = -(s0 + s1);
+                                }
+                                o[j] = dv;                      // du_k (stage N has no input: 0)
+                            } else {
+                                dv = dxk[j - 6];
+                            }
+                            const bool hc = has_comp(Nl, k, j);
+                            double dtl = 0, dll = 0, dtu = 0, dlu = 0;
+                            if (hc && bnd_lo(P, j) > -BOUND_INF) {
+                                const double l = lt[j], t = lt[24 + j];
+                                dtl = dv + r[j];
+                                dll = -(r[24 + j] + l * dtl) * fast_rcp(t);
+                                if (dll < 0 && l + al * dll < 0) al = -l * fast_rcp(dll);
+                                if (dtl < 0 && t + al * dtl < 0) al = -t * fast_rcp(dtl);
+                                a0 += l * t; a1 += l * dtl + t * dll; a2 += dll * dtl;
+                            }
+                            if (hc && bnd_hi(P, j) < BOUND_INF) {
+                                const double l = lt[12 + j], t = lt[36 + j];
+                                dtu = -dv + r[12 + j];
+                                dlu = -(r[36 + j] + l * dtu) * fast_rcp(t);
+                                if (dlu < 0 && l + al * dlu < 0) al = -l * fast_rcp(dlu);
+                                if (dtu < 0 && t + al * dtu < 0) al = -t * fast_rcp(dtu);
+                                a0 += l * t; a1 += l * dtu + t * dlu; a2 += dlu * dtu;
+                            }
+                            o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
+                            o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
+                        }
+                        r_al.at(lane) = al; r_a0.at(lane) = a0; r_a1.at(lane) = a1; r_a2.at(lane) = a2;
+                    });
+                }
+                if (ci == NCH - 1) {   // last window: publish the reductions over the whole horizon
+                    ex.sub([&](int lane) {
+                        ex.put1_min(sm.red[0], lane, r_al.at(lane)); ex.put1_sum(sm.red[1], lane, r_a0.at(lane));
+                        ex.put1_sum(sm.red[2], lane, r_a1.at(lane)); ex.put1_sum(sm.red[3], lane, r_a2.at(lane));
+                    });
+                }
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk0 <= Nl) {
@@ -1140,78 +1213,38 @@ struct Engine {
                     if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, c.w.G3, k0 - CH, k0 - 1, lane);
                     else copy_lanes<WO, O_DW, W3, WO, false, NL>(po, c.w.G3, k0 - CH, k0 - 1, lane);
                 }
+                if (!AFFINE) {
+                    // copies issued: the copy wavefronts now follow the recursion too and form
+                    // dpi_{k-1} = p_k + P_k dx_k, block b on wavefront b mod (NL / 64)
+                    const int wv = ex.uni(lane >> 6), l6 = lane & (WAVE - 1);
+                    for (int kb = k0 + wv * BLK; kb <= k1; kb += BLK * (NL / WAVE)) {
+                        const int ke = imin(kb + BLK - 1, k1), rows = ke - kb + 1;
+                        ex.await(&sm.prog, ke);
+                        if (l6 < rows * NX) {
+                            const int s = l6 / NX, j = l6 - s * NX, k = kb + s;
+                            const double *fac = v4 + (size_t)(k - k0) * LF;
+                            double *o = vo + (size_t)(k - k0) * WO;
+                            const double *dxk = o + 6;
+                            double v = 0.0;
+                            if (k >= 1) {
+                                double s0 = fac[(AFFINE ? 0 : O_PV) + j], s1 = 0.0;
+#pragma unroll
+                                for (int i = 0; i < NX; i += 2) { s0 += fac[(AFFINE ? 0 : O_PM) + j * 12 + i] * dxk[i]; s1 += fac[(AFFINE ? 0 : O_PM) + j * 12 + i + 1] * dxk[i + 1]; }
+                                v = s0 + s1;
+                            }
+                            o[18 + j] = v;                  // DPI slot of stage k holds dpi_{k-1}
+                        }
+                    }
+                }
             });
             PROF_ADD(PF_SEQ_FWD, ts);
-            PROF_T0(tx3);
-            ex.par([&](int lane) {
-                const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 18; e += NT) {
-                    const int s = e / 18, ci = e - s * 18, k = k0 + s;
-                    const double *fac = v4 + (size_t)s * LF;
-                    double *o = vo + (size_t)s * WO;
-                    const double *dxk = o + 6;
-                    double v = 0.0;
-                    if (ci < 6) {
-                        if (k < Nl) {
-                            v = vh[(size_t)s * WH + ci];
-#pragma unroll
-                            for (int j = 0; j < NX; j++) v += fac[O_K + ci * 12 + j] * dxk[j];
-                            v = -v;
-                        }
-                        o[ci] = v;                      // du_k (stage N has no input: 0)
-                    } else if (!AFFINE) {
-                        const int j = ci - 6;
-                        if (k >= 1) {
-                            v = fac[O_PV + j];
-#pragma unroll
-                            for (int i = 0; i < NX; i++) v += fac[O_PM + j * 12 + i] * dxk[i];
-                        }
-                        o[18 + j] = v;                  // DPI slot of stage k holds dpi_{k-1}
-                    }
-                }
-            });
-            ex.par([&](int lane) {
-                double al = 1.0, a0 = 0, a1 = 0, a2 = 0;
-                const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NB; e += NT) {
-                    const int s = e / NB, j = e - s * NB, k = k0 + s;
-                    const bool hc = has_comp(Nl, k, j);
-                    const double *lt = vlt + (size_t)s * WLT, *r = vr + (size_t)s * WR;
-                    double *o = vo + (size_t)s * WO;
-                    const double dv = o[j];
-                    double dtl = 0, dll = 0, dtu = 0, dlu = 0;
-                    if (hc && bnd_lo(P, j) > -BOUND_INF) {
-                        const double l = lt[j], t = lt[24 + j];
-                        dtl = dv + r[j];
-                        dll = -(r[24 + j] + l * dtl) * fast_rcp(t);
-                        if (dll < 0 && l + al * dll < 0) al = -l * fast_rcp(dll);
-                        if (dtl < 0 && t + al * dtl < 0) al = -t * fast_rcp(dtl);
-                        a0 += l * t; a1 += l * dtl + t * dll; a2 += dll * dtl;
-                    }
-                    if (hc && bnd_hi(P, j) < BOUND_INF) {
-                        const double l = lt[12 + j], t = lt[36 + j];
-                        dtu = -dv + r[12 + j];
-                        dlu = -(r[36 + j] + l * dtu) * fast_rcp(t);
-                        if (dlu < 0 && l + al * dlu < 0) al = -l * fast_rcp(dlu);
-                        if (dtu < 0 && t + al * dtu < 0) al = -t * fast_rcp(dtu);
-                        a0 += l * t; a1 += l * dtu + t * dlu; a2 += dlu * dtu;
-                    }
-                    o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
-                    o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
-                }
-                ex.put_min(sm.red[0], lane, al); ex.put_sum(sm.red[1], lane, a0); ex.put_sum(sm.red[2], lane, a1); ex.put_sum(sm.red[3], lane, a2);
-            });
-            alpha = fmin(alpha, ex.get_min(sm.red[0]));
-            s0 += ex.get_sum(sm.red[1]);
-            s1 += ex.get_sum(sm.red[2]);
-            s2 += ex.get_sum(sm.red[3]);
-            PROF_ADD(PF_X3, tx3);
             if (k1 == Nl) {   // last chunk: nothing left to hide the store behind
                 if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
                 else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
             }
         }
-        S[0] = s0; S[1] = s1; S[2] = s2;
+        S[0] = ex.get1(sm.red[1]); S[1] = ex.get1(sm.red[2]); S[2] = ex.get1(sm.red[3]);
+        const double alpha = ex.get1(sm.red[0]);
         PROF_ADD(PF_FWD, t0);
         return alpha;
     }

@@ -32,6 +32,10 @@ extern __shared__ __attribute__((aligned(16))) double g_pool[];
 // Stateless on purpose: inside a non-inlined pass the executor is reached through `this`, and a
 // data member (e.g. a cached lane id) would be re-loaded from the stack at every phase.
 // NWV wavefronts (one workgroup) cooperate on one simulation.
+#ifndef MPCB_POLL_SLEEP
+#define MPCB_POLL_SLEEP 2
+#endif
+
 template <int NWV>
 struct DevExec {
     static constexpr int NT = WAVE * NWV;
@@ -125,6 +129,23 @@ struct DevExec {
             __syncthreads();
         }
     }
+    // progress counter between the recursion wavefront and the one following it (LDS, same CU):
+    // a wavefront's LDS operations complete in issue order, so data written before post() is
+    // visible to whoever has seen the posted value.
+    __device__ __forceinline__ static void post(int *flag, int v)
+    {
+        // compiler-only ordering: the LDS unit executes one wavefront's DS instructions in issue order,
+        // so no s_waitcnt is needed between the data writes and the flag write
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ static void await(int *flag, int v)
+    {
+        if (NWV > 2) {   // with one or two wavefronts the recursion has finished before the follower starts
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(MPCB_POLL_SLEEP);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     // one step of a recursion that runs on a single wavefront inside overlap3's `mid`
     template <class F>
     __device__ __forceinline__ void sub(F &&f)
@@ -184,6 +205,10 @@ struct DevExec {
         for (int w = 1; w < NWV; w++) tot = op(tot, r[w]);
         return uni(tot);
     }
+    // single-wavefront variants (inside overlap3's `mid`): one result in r[0]
+    __device__ __forceinline__ static void put1_sum(double *r, int lane, double v) { const double t = wave_reduce(v, OpSum()); if (lane == 0) r[0] = t; }
+    __device__ __forceinline__ static void put1_min(double *r, int lane, double v) { const double t = wave_reduce(v, OpMin()); if (lane == 0) r[0] = t; }
+    __device__ __forceinline__ static double get1(const double *r) { return uni(r[0]); }
     __device__ __forceinline__ static double get_sum(const double *r) { return get(r, OpSum()); }
     __device__ __forceinline__ static double get_max(const double *r) { return get(r, OpMax()); }
     __device__ __forceinline__ static double get_min(const double *r) { return get(r, OpMin()); }

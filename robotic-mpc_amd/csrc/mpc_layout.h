@@ -149,6 +149,8 @@ struct Smem {
     InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
     Robot rb;
     double Pseam[3][144];  // lowest-stage P of the last three chunks of the factorisation sweep
+    int prog;              // progress of the state recursion (last finished stage), Ex::post / await
+    int prog_pad;
     double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)
     double pv[2][12];
     double Rt[36];      // R~ = H_uu + Gamma_u + B'MB

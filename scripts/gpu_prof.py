@@ -8,7 +8,7 @@ from robotic_mpc_amd import robots, config, engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 T = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
-lib = os.path.join(ROOT, "robotic-mpc_amd", "libmpcbatch_prof.so")
+lib = os.environ.get("MPCB_LIB") or os.path.join(ROOT, "robotic-mpc_amd", "libmpcbatch_prof.so")
 eng = engine.MpcBatchEngine(0, lib_path=lib)
 print("kernel info", eng.kernel_info())
 ch = robots.builtin_chain("ur10")

@@ -56,10 +56,12 @@ struct HostExec {
     template <class FG, class MID, class BG>
     void overlap3(FG &&fg, MID &&mid, BG &&bg)
     {
-        for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
-        mid();
         fg();
+        mid();   // mid and bg may follow fg's progress (post / await): fg has finished here
+        for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
     }
+    static void post(int *flag, int v) { *flag = v; }
+    static void await(int *flag, int v) { if (*flag < v) std::abort(); }
     template <class F>
     void sub(F &&f)
     {
@@ -74,6 +76,9 @@ struct HostExec {
     static void put_sum(double *r, int lane, double v) { r[0] = lane == 0 ? v : r[0] + v; }
     static void put_max(double *r, int lane, double v) { r[0] = lane == 0 ? v : fmax(r[0], v); }
     static void put_min(double *r, int lane, double v) { r[0] = lane == 0 ? v : fmin(r[0], v); }
+    static void put1_sum(double *r, int lane, double v) { put_sum(r, lane, v); }
+    static void put1_min(double *r, int lane, double v) { put_min(r, lane, v); }
+    static double get1(const double *r) { return r[0]; }
     static double get_sum(const double *r) { return r[0]; }
     static double get_max(const double *r) { return r[0]; }
     static double get_min(const double *r) { return r[0]; }
