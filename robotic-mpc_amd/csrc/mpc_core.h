@@ -203,6 +203,14 @@ struct Engine {
         ex.par([&](int lane) { copy_lanes<W, C0, LDG, LDL, LOAD, NT>(l, g, k_lo, k_hi, lane); });
         PROF_ADD(PF_IO, t0);
     }
+    // several rectangle copies in ONE phase (one barrier, the loads of all rectangles in flight together)
+    template <class F>
+    MPC_HD void copies(F &&f)
+    {
+        PROF_T0(t0);
+        ex.par([&](int lane) { f(lane, std::integral_constant<int, NT>{}); });
+        PROF_ADD(PF_IO, t0);
+    }
     template <int W, int C0, int LDG>
     MPC_HD void load_rect(double *l, const double *g, int k_lo, int k_hi)
     {
@@ -241,8 +249,11 @@ struct Engine {
             double *v1 = ex.pool();                       // rows lo..hi, W1
             double *v5 = v1 + (size_t)(CH + 2) * W1;   // rows lo..hi, 60
             double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, W2
-            load_rect<W1, 0, W1>(v1, c.w.G1, lo, hi);
-            if (sqp_mult) load_rect<60, 0, W5>(v5, c.w.G5, lo, hi);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, lo, hi, lane);
+                if (sqp_mult) copy_lanes<60, 0, W5, 60, true, NL>(v5, c.w.G5, lo, hi, lane);
+            });
             if (do_update) {
                 ex.par([&](int lane) {
                     const int rows = hi - lo + 1;
@@ -340,11 +351,14 @@ struct Engine {
                 ri = fmax(ri, ex.get_max(sm.red[2]));
                 rc = fmax(rc, ex.get_max(sm.red[3]));
             }
-            if (do_update) {
-                copy_rect<18, 0, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1), c.w.G1, k0, k1);
-                if (sqp_mult) copy_rect<60, 0, W5, 60, false>(const_cast<double *>(v5 + (size_t)(k0 - lo) * 60), c.w.G5, k0, k1);
-            }
-            copy_rect<W2_LIN, 0, W2, W2, false>(const_cast<double *>(v2), c.w.G2, k0, k1);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                if (do_update) {
+                    copy_lanes<18, 0, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1, c.w.G1, k0, k1, lane);
+                    if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, lane);
+                }
+                copy_lanes<W2_LIN, 0, W2, W2, false, NL>(v2, c.w.G2, k0, k1, lane);
+            });
         }
         if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
         PROF_ADD(PF_NLP, t0);
@@ -414,9 +428,12 @@ struct Engine {
             double *v2 = v3d + (size_t)(CH + 2) * W3D;  // rows k0..k1, compact [R..GV] (60)
             double *v3r = v2 + (size_t)CH * W2_LIN;     // rows k0..k1, RG|RD|RM
             double *vg = v3r + (size_t)CH * W3R;        // rows k0..k1, Gamma(12) | gt(18) | rb(12)
-            load_rect<W1, 0, W1>(v1, c.w.G1, lo, hi);
-            if (mode == 1) load_rect<W3D, O_DW, W3>(v3d, c.w.G3, lo, hi);
-            load_rect<W2_LIN, 0, W2>(v2, c.w.G2, k0, k1);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, lo, hi, lane);
+                if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, c.w.G3, lo, hi, lane);
+                copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, c.w.G2, k0, k1, lane);
+            });
             PROF_T0(tx);
             ex.par([&](int lane) {
                 const int rows = hi - lo + 1;
@@ -542,10 +559,13 @@ struct Engine {
             nm = fmax(nm, ex.get_max(sm.red[3]));
             smu += ex.get_sum(sm.red[4]);
             PROF_ADD(PF_X1, tx);
-            copy_rect<78, O_QW, W1, W1, false>(const_cast<double *>(v1 + (size_t)(k0 - lo) * W1 + O_QW), c.w.G1, k0, k1);
-            copy_rect<10, 0, W2, W2_LIN, false>(const_cast<double *>(v2), c.w.G2, k0, k1);        // r (unchanged) and y
-            copy_rect<WG, O_GAM, W2, WG, false>(const_cast<double *>(vg), c.w.G2, k0, k1);        // Gamma | gt | rb
-            copy_rect<W3R, 0, W3, W3R, false>(const_cast<double *>(v3r), c.w.G3, k0, k1);         // RG | RD | RM
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<78, O_QW, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, lane);
+                copy_lanes<10, 0, W2, W2_LIN, false, NL>(v2, c.w.G2, k0, k1, lane);        // r (unchanged) and y
+                copy_lanes<WG, O_GAM, W2, WG, false, NL>(vg, c.w.G2, k0, k1, lane);        // Gamma | gt | rb
+                copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, c.w.G3, k0, k1, lane);         // RG | RD | RM
+            });
         }
         nrm[0] = ng; nrm[1] = nb; nrm[2] = nd; nrm[3] = nm;
         *smu_out = smu;
@@ -893,12 +913,15 @@ struct Engine {
             double *vlt, *v3, *vgr, *vk, *vw, *vc, *orm, *ohp;
             carve(0, vlt, v3, vgr, vk, vw, vc, orm, ohp);
             const int f0 = imax(Nl - CH + 1, 0);
-            load_rect<WLT, O_QLAM, W1>(vlt, c.w.G1, f0, Nl);
-            copy_rect<42, 0, W3, L3, true>(v3, c.w.G3, f0, Nl);
-            copy_rect<48, O_DLAM, W3, L3, true>(v3 + C_DLAM, c.w.G3, f0, Nl);
-            load_rect<WGR, O_GT, W2>(vgr, c.w.G2, f0, Nl);
-            load_rect<WK, O_K, W4>(vk, c.w.G4, f0, Nl);
-            load_rect<WW, O_WV, W4>(vw, c.w.G4, f0, Nl);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(vlt, c.w.G1, f0, Nl, lane);
+                copy_lanes<42, 0, W3, L3, true, NL>(v3, c.w.G3, f0, Nl, lane);
+                copy_lanes<48, O_DLAM, W3, L3, true, NL>(v3 + C_DLAM, c.w.G3, f0, Nl, lane);
+                copy_lanes<WGR, O_GT, W2, WGR, true, NL>(vgr, c.w.G2, f0, Nl, lane);
+                copy_lanes<WK, O_K, W4, WK, true, NL>(vk, c.w.G4, f0, Nl, lane);
+                copy_lanes<WW, O_WV, W4, WW, true, NL>(vw, c.w.G4, f0, Nl, lane);
+            });
         }
         for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
             const int k0 = imax(k1 - CH + 1, 0);
@@ -1019,8 +1042,11 @@ struct Engine {
                 }
             });
             if (k0 == 0) {
-                copy_rect<WRM, O_RM, W3, WRM, false>(orm, c.w.G3, k0, k1);
-                copy_rect<WHP, O_HU, W4, WHP, false>(ohp, c.w.G4, k0, k1);
+                copies([&](int lane, auto nl) {
+                    constexpr int NL = decltype(nl)::value;
+                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(orm, c.w.G3, k0, k1, lane);
+                    copy_lanes<WHP, O_HU, W4, WHP, false, NL>(ohp, c.w.G4, k0, k1, lane);
+                });
             }
         }
         PROF_ADD(PF_BWD, t0);
@@ -1072,10 +1098,13 @@ struct Engine {
         {
             double *q4 = pool, *qrb = q4 + (size_t)CH * LF, *qlt = qrb + (size_t)CH * WRB, *qr = qlt + (size_t)CH * WLT;
             const int e1 = imin(CH - 1, Nl);
-            load_rect<LF, 0, W4>(q4, c.w.G4, 0, e1);
-            load_rect<WRB, O_RB, W2>(qrb, c.w.G2, 0, e1);
-            load_rect<WLT, O_QLAM, W1>(qlt, c.w.G1, 0, e1);
-            load_rect<WR, O_RD, W3>(qr, c.w.G3, 0, e1);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<LF, 0, W4, LF, true, NL>(q4, c.w.G4, 0, e1, lane);
+                copy_lanes<WRB, O_RB, W2, WRB, true, NL>(qrb, c.w.G2, 0, e1, lane);
+                copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(qlt, c.w.G1, 0, e1, lane);
+                copy_lanes<WR, O_RD, W3, WR, true, NL>(qr, c.w.G3, 0, e1, lane);
+            });
         }
         for (int ci = 0; ci < NCH; ci++) {
             const int k0 = ci * CH, k1 = imin(k0 + CH - 1, Nl);
@@ -1311,8 +1340,11 @@ struct Engine {
             double *v1 = ex.pool();                        // rows k0..hi, W1
             double *vm = v1 + (size_t)(CH + 1) * W1;    // rows k0..k1, MW
             double *vt = vm + (size_t)CH * WMW;         // rows k0..k1, scratch r(5)
-            load_rect<W1, 0, W1>(v1, c.w.G1, k0, hi);
-            load_rect<WMW, O_MW, W5>(vm, c.w.G5, k0, k1);
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
+                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, k0, hi, lane);
+                copy_lanes<WMW, O_MW, W5, WMW, true, NL>(vm, c.w.G5, k0, k1, lane);
+            });
             if (update_weights) {
                 ex.par([&](int lane) {
                     const int rows = k1 - k0 + 1;
