@@ -141,7 +141,7 @@ struct DevExec {
     }
     __device__ __forceinline__ static void await(int *flag, int v)
     {
-        if (NWV > 2) {   // with one or two wavefronts the recursion has finished before the follower starts
+        if (NWV > 1) {   // with a single wavefront the recursion has finished before the follower starts
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(MPCB_POLL_SLEEP);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

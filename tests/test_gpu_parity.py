@@ -73,6 +73,26 @@ def test_engine_matches_oracle(eng, orc, ur10, ur10_rb, N, T, solver, B):
         _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
 
 
+@pytest.mark.parametrize("waves,sims_per_cu", [(1, 1), (2, 2), (2, 1), (8, 1), (4, 2), (1, 4)])
+@pytest.mark.parametrize("N,T,solver", [(100, 0.2, "SQP_RTI"), (33, 0.2, "SQP")])
+def test_every_launch_geometry_matches_oracle(orc, ur10, ur10_rb, monkeypatch, waves, sims_per_cu, N, T, solver):
+    """1, 2, 4, 8 wavefronts per simulation and the smaller LDS pools of several simulations per CU
+    (what batches > 256 get) run the same template with different role layouts (Ex::overlap3)."""
+    from robotic_mpc_amd import engine
+
+    monkeypatch.setenv("MPCB_WAVES_PER_SIM", str(waves))
+    monkeypatch.setenv("MPCB_SIMS_PER_CU", str(sims_per_cu))
+    e = engine.MpcBatchEngine(0)
+    try:
+        cfgs = _jitter(3, seed=waves, prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
+        out = e.run(cfgs, ur10)
+        assert e.launch_info()["waves_per_sim"] == waves
+        for i, c in enumerate(cfgs):
+            _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+    finally:
+        e.close()
+
+
 def test_active_bounds_and_heterogeneous_parameters(eng, orc, ur10, ur10_rb):
     cfgs = [
         _cfg(prediction_horizon=15, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
