@@ -371,19 +371,26 @@ struct Engine {
     MPC_HD double stat_elem(int k, int cidx, const double *r1, const double *r2, bool with_delta, const double *pk,
                             const double *pm) const
     {
+        if (cidx < 6) return stat_cls<0>(k, cidx, r1, r2, with_delta, pk, pm);
+        if (cidx < 12) return stat_cls<1>(k, cidx - 6, r1, r2, with_delta, pk, pm);
+        return stat_cls<2>(k, cidx - 12, r1, r2, with_delta, pk, pm);
+    }
+    // CLS 0: input u_j, 1: joint position q_j, 2: joint velocity v_j  (component cidx = 6 CLS + j)
+    template <int CLS>
+    MPC_HD double stat_cls(int k, int j, const double *r1, const double *r2, bool with_delta, const double *pk,
+                           const double *pm) const
+    {
         const InstParams &P = ex.smem().P;
         double val = 0.0;
-        if (cidx < 6) {
+        if (CLS == 0) {
             if (k >= N) return 0.0;
-            const int j = cidx;
             double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
             if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
             const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
             val = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
             val += P.b1[j] * pk[j] + P.b2[j] * pk[6 + j];
-        } else if (cidx < 12) {
+        } else if (CLS == 1) {
             if (k == 0) return 0.0;
-            const int j = cidx - 6;
             if (k < N) {
                 double s = 0.0;
 #pragma unroll
@@ -393,7 +400,6 @@ struct Engine {
             val -= pm[j];
         } else {
             if (k == 0) return 0.0;
-            const int j = cidx - 12;
             if (k < N) {
                 double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
                 if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
@@ -474,6 +480,8 @@ struct Engine {
                 ex.put_sum(sm.red[5], lane, ncl);
             });
             if (mode == 0) nc += ex.get_sum(sm.red[5]);
+            PROF_ADD(PF_X1, tx);
+            PROF_T0(ty);
             // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -492,63 +500,80 @@ struct Engine {
                     r2[O_Y + i] = P.w_task[i] * v;
                 }
             });
-            // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg
+            PROF_ADD(PF_X2, ty);
+            PROF_T0(tz);
+            // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg.  Four kinds of rows -- u, q, v
+            // components of the stationarity residual and the dynamics residual -- each have their own
+            // formulas: a wavefront works on ONE kind at a time, so no lane diverges from its neighbours.
             ex.par([&](int lane) {
                 double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NW; e += NT) {
-                    const int s = e / NW, ci = e - s * NW, k = k0 + s;
-                    const double *r1 = v1 + (size_t)(k - lo) * W1;
-                    const double *r2 = v2 + (size_t)s * W2_LIN;
-                    const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
-                    double *o3 = v3r + (size_t)s * W3R, *og = vg + (size_t)s * 42;
-                    double rg = stat_elem(k, ci, r1, r2, true, pk, pm);
-                    double gt = rg;
-                    if (ci < NB) {
-                        const bool hc = has_comp(Nl, k, ci);
-                        const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
-                        const double v = hc ? r1[ci < 6 ? O_U + ci : O_X + ci - 6] : 0.0, dv = r1[O_QW + ci];
-                        double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
-                        gt = rg;
-                        if (blo) {
-                            const double l = r1[O_QLAM + ci], t = r1[O_QT + ci], it = fast_rcp(t);
-                            rdl = dv - (bnd_lo(P, ci) - v) - t;
-                            rml = l * t;
-                            rg -= l; gt -= l;
-                            gam += l * it;
-                            gt += (rml + l * rdl) * it;
-                            a_mu += rml;
-                            a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                constexpr int NWVc = NT / WAVE, NR = 4;
+                constexpr int PARTS = NWVc >= NR ? NWVc / NR : 1, RSTEP = NWVc >= NR ? NR : NWVc;
+                const int w = ex.uni(lane >> 6), l6 = lane & (WAVE - 1);
+                const int part = NWVc >= NR ? w / NR : 0;
+                auto stat_rows = [&](auto cls) {
+                    constexpr int CLS = decltype(cls)::value;
+                    for (int e = l6 + WAVE * part; e < rows * 6; e += WAVE * PARTS) {
+                        const int s = e / 6, j = e - s * 6, ci = CLS * 6 + j, k = k0 + s;
+                        const double *r1 = v1 + (size_t)(k - lo) * W1;
+                        const double *r2 = v2 + (size_t)s * W2_LIN;
+                        const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
+                        double *o3 = v3r + (size_t)s * W3R, *og = vg + (size_t)s * 42;
+                        double rg = stat_cls<CLS>(k, j, r1, r2, true, pk, pm);
+                        double gt = rg;
+                        if (CLS < 2) {
+                            const bool hc = has_comp(Nl, k, ci);
+                            const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                            const double v = hc ? r1[CLS == 0 ? O_U + j : O_X + j] : 0.0, dv = r1[O_QW + ci];
+                            double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                            if (blo) {
+                                const double l = r1[O_QLAM + ci], t = r1[O_QT + ci], it = fast_rcp(t);
+                                rdl = dv - (bnd_lo(P, ci) - v) - t;
+                                rml = l * t;
+                                rg -= l; gt -= l;
+                                gam += l * it;
+                                gt += (rml + l * rdl) * it;
+                                a_mu += rml;
+                                a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                            }
+                            if (bhi) {
+                                const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci], it = fast_rcp(t);
+                                rdu = (bnd_hi(P, ci) - v) - dv - t;
+                                rmu = l * t;
+                                rg += l; gt += l;
+                                gam += l * it;
+                                gt -= (rmu + l * rdu) * it;
+                                a_mu += rmu;
+                                a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
+                            }
+                            o3[O_RD + ci] = rdl; o3[O_RD + 12 + ci] = rdu;
+                            o3[O_RM + ci] = rml; o3[O_RM + 12 + ci] = rmu;
+                            og[ci] = gam;
                         }
-                        if (bhi) {
-                            const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci], it = fast_rcp(t);
-                            rdu = (bnd_hi(P, ci) - v) - dv - t;
-                            rmu = l * t;
-                            rg += l; gt += l;
-                            gam += l * it;
-                            gt -= (rmu + l * rdu) * it;
-                            a_mu += rmu;
-                            a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
+                        o3[O_RG + ci] = rg;
+                        og[12 + ci] = gt;
+                        a_g = fmax(a_g, fabs(rg));
+                    }
+                };
+                for (int role = NWVc >= NR ? w % NR : w; role < NR; role += RSTEP) {
+                    if (role == 0) stat_rows(std::integral_constant<int, 0>{});
+                    else if (role == 1) stat_rows(std::integral_constant<int, 1>{});
+                    else if (role == 2) stat_rows(std::integral_constant<int, 2>{});
+                    else {
+                        for (int e = l6 + WAVE * part; e < rows * NX; e += WAVE * PARTS) {
+                            const int s = e / NX, i = e - s * NX, k = k0 + s;
+                            double v = 0.0;
+                            if (k < Nl) {
+                                const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW, *dn = dw + W1;
+                                if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
+                                else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
+                                v += v2[(size_t)s * W2_LIN + O_BD + i] - dn[6 + i];
+                                a_b = fmax(a_b, fabs(v));
+                            }
+                            vg[(size_t)s * WG + 30 + i] = v;
                         }
-                        o3[O_RD + ci] = rdl; o3[O_RD + 12 + ci] = rdu;
-                        o3[O_RM + ci] = rml; o3[O_RM + 12 + ci] = rmu;
-                        og[ci] = gam;
                     }
-                    o3[O_RG + ci] = rg;
-                    og[12 + ci] = gt;
-                    a_g = fmax(a_g, fabs(rg));
-                }
-                for (int e = lane; e < rows * NX; e += NT) {
-                    const int s = e / NX, i = e - s * NX, k = k0 + s;
-                    double v = 0.0;
-                    if (k < Nl) {
-                        const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW, *dn = dw + W1;
-                        if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
-                        else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
-                        v += v2[(size_t)s * W2_LIN + O_BD + i] - dn[6 + i];
-                        a_b = fmax(a_b, fabs(v));
-                    }
-                    vg[(size_t)s * WG + 30 + i] = v;
                 }
                 ex.put_max(sm.red[0], lane, a_g); ex.put_max(sm.red[1], lane, a_b); ex.put_max(sm.red[2], lane, a_d); ex.put_max(sm.red[3], lane, a_m);
                 ex.put_sum(sm.red[4], lane, a_mu);
@@ -558,7 +583,7 @@ struct Engine {
             nd = fmax(nd, ex.get_max(sm.red[2]));
             nm = fmax(nm, ex.get_max(sm.red[3]));
             smu += ex.get_sum(sm.red[4]);
-            PROF_ADD(PF_X1, tx);
+            PROF_ADD(PF_X3, tz);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<78, O_QW, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, lane);
@@ -1120,7 +1145,6 @@ struct Engine {
             const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
             // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
             // does not depend on dx_k
-            PROF_T0(tx2);
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
                 for (int e = lane; e < rows * 6; e += NT) {
@@ -1135,10 +1159,8 @@ struct Engine {
                     h[12 + i] = vrb[(size_t)s * WRB + 6 + i] - P.b2[i] * v;
                 }
             });
-            PROF_ADD(PF_X2, tx2);
             PROF_T0(ts);
             ex.overlap3([&]() {
-            PROF_T0(tx3);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
@@ -1171,7 +1193,6 @@ struct Engine {
                 });
                 if (k < Nl) cur = nxt;
             }
-            PROF_ADD(PF_X3, tx3);
             }, [&]() {
                 // wavefront 1 follows the recursion block by block: du_k = -(R~^-1 h_u + K dx_k), then
                 // dlam, dt (HPIPM compute_lam_t), largest feasible step, centering sums -- one phase,
