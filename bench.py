@@ -187,6 +187,7 @@ def main():
     algo_bytes = bytes_per_mpc_step(pb.N) * steps_per_pass
     achieved = algo_bytes / avg_kernel_s / 1e9
     qp_iters = float(bufs["qp_iter"].double().mean().item())
+    qp_hist = torch.bincount(bufs["qp_iter"].flatten().long().clamp(max=15), minlength=16).tolist()   # last bin: >= 15
     failures = int((bufs["status"] != 0).sum().item())
     # secondary: fp64 VALU estimate: ipm_iters*N*1e4 + n_lin*(N+1)*3e3 flop per MPC step
     flops_step = qp_iters * pb.N * 1.0e4 + 1.0 * (pb.N + 1) * 3.0e3
@@ -203,7 +204,8 @@ def main():
                                f"{pb.Nsim} closed-loop steps, {args.solver}, flat surface, q_0 jitter U(-0.1,0.1) rng({rank})",
                    "batch_per_gpu": args.batch, "horizon": pb.N, "closed_loop_steps": pb.Nsim, "solver": args.solver,
                    "parallelism": f"{world} GPU x {args.batch} workgroups (one simulation each) x {geo['waves_per_sim']} wavefronts", "gather": gather_note,
-                   "mean_qp_iters_per_step": qp_iters, "solver_failures": failures},
+                   "mean_qp_iters_per_step": qp_iters, "qp_iter_histogram_rank0": qp_hist,
+                   "ipm_iterations_per_sec": value * qp_iters, "solver_failures": failures},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mpc_rollout_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
