@@ -63,7 +63,7 @@ typedef struct {
 
 /* Per-simulation parameter record, MPCB_NPARAM doubles (simulator.py:18-35):
  *   [0] dt  [1] tol (acados nlp tol, 1e-6)  [2] qp_tol (trajectory_optimizer.py:63)
- *   [3] w_u [4] w_qddot [5] px_ref [6] vy_ref [7] reserved
+ *   [3] w_u [4] w_qddot [5] px_ref [6] vy_ref [7] plant integrator (0 RK4, 1 Euler, 2 RK2, 3 RK3; simulation_model.py:39-49)
  *   [8..13] wcv   [14..19] q_0   [20..25] qdot_0   [26..31] q_min   [32..37] q_max
  *   [38..43] qdot_min (lbu)   [44..49] qdot_max (ubu)
  *   [50..55] surface_coeffs a,b,c,d,e,f (surface.py:14-17)

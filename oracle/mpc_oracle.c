@@ -277,6 +277,27 @@ void orc_rk4(const double *wcv, double dt, const double *z, const double *u, dou
         zn[i] = z[i] + (dt / 6) * k1[i] + (dt / 3) * k2[i] + (dt / 3) * k3[i] + (dt / 6) * k4[i];
 }
 
+/* simulation_model.py:93-109: Euler, RK2 (midpoint), RK3; anything else: RK4 */
+void orc_plant_step(int integrator, const double *wcv, double dt, const double *z, const double *u, double *zn)
+{
+    double k1[12], k2[12], k3[12], t[12];
+    if (integrator < 1 || integrator > 3) { orc_rk4(wcv, dt, z, u, zn); return; }
+    plant_f(wcv, z, u, k1);
+    if (integrator == 1) {
+        for (int i = 0; i < 12; i++) zn[i] = z[i] + dt * k1[i];
+        return;
+    }
+    for (int i = 0; i < 12; i++) t[i] = z[i] + 0.5 * dt * k1[i];
+    plant_f(wcv, t, u, k2);
+    if (integrator == 2) {
+        for (int i = 0; i < 12; i++) zn[i] = z[i] + dt * k2[i];
+        return;
+    }
+    for (int i = 0; i < 12; i++) t[i] = z[i] - dt * k1[i] + 2.0 * dt * k2[i];
+    plant_f(wcv, t, u, k3);
+    for (int i = 0; i < 12; i++) zn[i] = z[i] + (dt / 6) * (k1[i] + 4.0 * k2[i] + k3[i]);
+}
+
 /* r = [g - g_ref (5); u (6); qddot_k (6)], Jr = d r / d [u; q; qdot]
  * (trajectory_optimizer.py:107-126,154-155; prediction_model.py:322-326). */
 void orc_stage_residual(const orc_robot *rb, const orc_params *p, const double *x, const double *u,
@@ -1101,7 +1122,7 @@ int orc_run(const orc_robot *rb, const orc_params *p, orc_output *o)
         if (o->residuals) memcpy(o->residuals + (size_t)i * 4, res, sizeof res);
         if (o->cost) o->cost[i] = cost;
         if (o->solver_time) o->solver_time[i] = t1 - t0;
-        orc_rk4(p->wcv, p->dt, z, u, zn); /* simulation_model.py:85-91 */
+        orc_plant_step(p->integrator, p->wcv, p->dt, z, u, zn); /* simulation_model.py:85-91 */
         memcpy(z, zn, sizeof z);
         log_state(rb, o, T1, i + 1, z, u);
     }

@@ -53,6 +53,7 @@ typedef struct {
     double w_u, w_qddot, px_ref, vy_ref;
     double coeffs[6]; /* a b c d e f, surface.py:14-17 */
     double w_task[5]; /* trajectory_optimizer.py:44-48 (all 50.0) */
+    int integrator;   /* plant integrator, simulation_model.py:39-49: 0 RK4 (simulator.py:85), 1 Euler, 2 RK2, 3 RK3 */
 } orc_params;
 
 /* Per-instance outputs, C-contiguous [row][time] like the reference's logs
@@ -84,6 +85,7 @@ void orc_task_g(const orc_robot *rb, const double *coeffs, const double *q, cons
 /* ---- model (prediction_model.py:87-115, 317-326) ---- */
 void orc_lti(const double *wcv, double Ts, double *a12, double *a22, double *b1, double *b2);
 void orc_rk4(const double *wcv, double dt, const double *z, const double *u, double *znext);
+void orc_plant_step(int integrator, const double *wcv, double dt, const double *z, const double *u, double *znext);
 
 /* ---- stage residual / Jacobian (trajectory_optimizer.py:131-160) ---- */
 void orc_stage_residual(const orc_robot *rb, const orc_params *p, const double *x, const double *u,

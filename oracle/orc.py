@@ -31,7 +31,7 @@ class Params(C.Structure):
         ("wcv", C.c_double * 6), ("q0", C.c_double * 6), ("qdot0", C.c_double * 6),
         ("qmin", C.c_double * 6), ("qmax", C.c_double * 6), ("umin", C.c_double * 6), ("umax", C.c_double * 6),
         ("w_u", C.c_double), ("w_qddot", C.c_double), ("px_ref", C.c_double), ("vy_ref", C.c_double),
-        ("coeffs", C.c_double * 6), ("w_task", C.c_double * 5),
+        ("coeffs", C.c_double * 6), ("w_task", C.c_double * 5), ("integrator", C.c_int),
     ]
 
 
@@ -85,6 +85,7 @@ def make_params(cfg: Dict) -> Params:
         getattr(p, k)[:] = [float(v) for v in cfg[k]]
     p.w_u = float(cfg["w_u"]); p.w_qddot = float(cfg["w_qddot"])
     p.px_ref = float(cfg["px_ref"]); p.vy_ref = float(cfg["vy_ref"])
+    p.integrator = int(cfg.get("plant_integrator", 0))
     return p
 
 
@@ -122,6 +123,15 @@ def stage_residual(rb: Robot, p: Params, x, u):
     lib().orc_stage_residual(C.byref(rb), C.byref(p), _ptr(np.ascontiguousarray(x, dtype=np.float64)),
                              _ptr(np.ascontiguousarray(u, dtype=np.float64)), _ptr(r), _ptr(Jr))
     return r, Jr
+
+
+def plant_step(integrator: int, wcv, dt, z, u) -> np.ndarray:
+    """simulation_model.py:93-117: 0 RK4, 1 Euler, 2 RK2, 3 RK3."""
+    out = np.zeros(12)
+    lib().orc_plant_step(C.c_int(integrator), _ptr(np.ascontiguousarray(wcv, dtype=np.float64)), C.c_double(dt),
+                         _ptr(np.ascontiguousarray(z, dtype=np.float64)), _ptr(np.ascontiguousarray(u, dtype=np.float64)),
+                         _ptr(out))
+    return out
 
 
 def rk4(wcv, dt, z, u) -> np.ndarray:

@@ -25,7 +25,12 @@ OPTIONAL_DEFAULTS = {
     "surface_coeffs": None, "solver_options": None, "w_u": 0.01, "px_ref": 0.40, "vy_ref": 0.05, "scene": True,
 }
 # Extensions beyond the reference's signature: all optional.
-EXTENSION_DEFAULTS = {"translation_ee_t": (0.0, 0.0, 0.1), "urdf_path": None, "ee_frame": None}
+EXTENSION_DEFAULTS = {"translation_ee_t": (0.0, 0.0, 0.1), "urdf_path": None, "ee_frame": None,
+                      # plant integrator of simulation_model.Robot (simulation_model.py:13,39-51); the reference's
+                      # Simulator hard-codes "RK4" (simulator.py:85)
+                      "integration_method": "RK4"}
+# codes of the parameter record (include/mpcbatch.h [7]); RK4 = 0 keeps default records unchanged
+PLANT_INTEGRATORS = {"RK4": 0, "Euler": 1, "RK2": 2, "RK3": 3}
 
 # surface.py:14-17
 DEFAULT_SURFACE_COEFFS = {"a": -0.15, "b": 0.15, "c": -0.01, "d": 0.01, "e": 0.01, "f": 0.0}
@@ -154,6 +159,8 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
     wcv = _vec6(cfg, "wcv")
     if np.any(wcv <= 0):
         raise ValueError("wcv must be positive (prediction_model.py:94 divides by it)")
+    if cfg["integration_method"] not in PLANT_INTEGRATORS:
+        raise ValueError(f"Unknown integration method: {cfg['integration_method']}")  # simulation_model.py:51
     t_ee = np.asarray(cfg["translation_ee_t"], dtype=np.float64).reshape(-1)
     if t_ee.shape != (3,):
         raise ValueError("translation_ee_t must have 3 entries")
@@ -173,6 +180,7 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
         "coeffs_dict": coeffs,
         "w_task": np.array(TASK_WEIGHTS, dtype=np.float64),
         "t_ee": t_ee,
+        "integration_method": cfg["integration_method"], "plant_integrator": PLANT_INTEGRATORS[cfg["integration_method"]],
         # stored-but-unused by the OCP, exactly as in the reference
         "surface_limits": cfg["surface_limits"], "surface_origin": cfg["surface_origin"],
         "surface_orientation_rpy": cfg["surface_orientation_rpy"],

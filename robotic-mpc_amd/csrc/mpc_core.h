@@ -1562,15 +1562,30 @@ struct Engine {
                     const int j = lane;
                     const double u = w.G1[O_U + j], wc = P.wcv[j], dt = P.dt;
                     const double q = sm.xhat[j], v = sm.xhat[6 + j];
+                    // simulation_model.py:93-117: Euler / RK2 (midpoint) / RK3 / RK4 of z' = [qdot; -W(qdot - u)]
+                    const int integ = (int)P.integ;
                     const double k1q = v, k1v = -wc * v + wc * u;
                     const double v2 = v + 0.5 * dt * k1v;
                     const double k2q = v2, k2v = -wc * v2 + wc * u;
-                    const double v3 = v + 0.5 * dt * k2v;
-                    const double k3q = v3, k3v = -wc * v3 + wc * u;
-                    const double v4 = v + dt * k3v;
-                    const double k4q = v4, k4v = -wc * v4 + wc * u;
-                    sm.logv[24 + j] = q + (dt / 6) * k1q + (dt / 3) * k2q + (dt / 3) * k3q + (dt / 6) * k4q;
-                    sm.logv[30 + j] = v + (dt / 6) * k1v + (dt / 3) * k2v + (dt / 3) * k3v + (dt / 6) * k4v;
+                    double qn, vn;
+                    if (integ == 1) {
+                        qn = q + dt * k1q; vn = v + dt * k1v;
+                    } else if (integ == 2) {
+                        qn = q + dt * k2q; vn = v + dt * k2v;
+                    } else if (integ == 3) {
+                        const double v3 = v - dt * k1v + 2.0 * dt * k2v;
+                        const double k3q = v3, k3v = -wc * v3 + wc * u;
+                        qn = q + (dt / 6) * (k1q + 4.0 * k2q + k3q); vn = v + (dt / 6) * (k1v + 4.0 * k2v + k3v);
+                    } else {
+                        const double v3 = v + 0.5 * dt * k2v;
+                        const double k3q = v3, k3v = -wc * v3 + wc * u;
+                        const double v4 = v + dt * k3v;
+                        const double k4q = v4, k4v = -wc * v4 + wc * u;
+                        qn = q + (dt / 6) * k1q + (dt / 3) * k2q + (dt / 3) * k3q + (dt / 6) * k4q;
+                        vn = v + (dt / 6) * k1v + (dt / 3) * k2v + (dt / 3) * k3v + (dt / 6) * k4v;
+                    }
+                    sm.logv[24 + j] = qn;
+                    sm.logv[30 + j] = vn;
                     sm.u0[j] = u;
                 }
                 if (lane == 8) {

@@ -85,7 +85,7 @@ struct Robot {
 
 // Per-instance parameters, one record per instance in HBM (packed by pack_inst_params).
 struct InstParams {
-    double dt, tol, qp_tol, w_u, w_qddot, px_ref, vy_ref, pad0;
+    double dt, tol, qp_tol, w_u, w_qddot, px_ref, vy_ref, integ;   // integ: plant integrator code
     double wcv[6], q0[6], qdot0[6], qmin[6], qmax[6], umin[6], umax[6];
     double coeffs[6];   // a b c d e f   (surface.py:14-17)
     double w_task[5];   // trajectory_optimizer.py:44-48

@@ -16,7 +16,7 @@ namespace mpcb {
 inline void pack_inst_params(const double *p, InstParams *P)
 {
     P->dt = p[0]; P->tol = p[1]; P->qp_tol = p[2]; P->w_u = p[3]; P->w_qddot = p[4];
-    P->px_ref = p[5]; P->vy_ref = p[6]; P->pad0 = 0.0; P->pad1 = 0.0;
+    P->px_ref = p[5]; P->vy_ref = p[6]; P->integ = p[7]; P->pad1 = 0.0;
     for (int j = 0; j < 6; j++) {
         P->wcv[j] = p[8 + j]; P->q0[j] = p[14 + j]; P->qdot0[j] = p[20 + j];
         P->qmin[j] = p[26 + j]; P->qmax[j] = p[32 + j]; P->umin[j] = p[38 + j]; P->umax[j] = p[44 + j];

@@ -61,3 +61,16 @@ def test_emulated_engine_active_bounds_and_batch(orc, ur10, ur10_rb):
         np.testing.assert_allclose(out["u"][i], ref["u"], atol=1e-9, rtol=0)
         np.testing.assert_array_equal(out["status"][i], ref["status"])
     assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6  # the bound is really hit
+
+
+@pytest.mark.parametrize("method", ["Euler", "RK2", "RK3"])
+def test_emulated_plant_integrators(orc, ur10, ur10_rb, method):
+    """simulation_model.py:39-49: the plant integrator is a per-simulation parameter."""
+    import emu
+
+    cfg = _cfg(prediction_horizon=8, simulation_time=0.1, integration_method=method)
+    ref = orc.run(ur10_rb, orc.make_params(cfg))
+    out = emu.run([cfg], ur10, waves=4)
+    np.testing.assert_allclose(out["z"][0], ref["z"], atol=1e-11, rtol=0)
+    rk4 = orc.run(ur10_rb, orc.make_params(_cfg(prediction_horizon=8, simulation_time=0.1)))
+    assert np.abs(rk4["z"] - ref["z"]).max() > 1e-6   # the option does change the closed loop

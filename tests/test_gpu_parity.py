@@ -107,6 +107,15 @@ def test_active_bounds_and_heterogeneous_parameters(eng, orc, ur10, ur10_rb):
     assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6
 
 
+def test_plant_integrators_per_simulation(eng, orc, ur10, ur10_rb):
+    """Euler / RK2 / RK3 / RK4 plant (simulation_model.py:39-49,93-117) mixed inside ONE batch."""
+    cfgs = [_cfg(prediction_horizon=12, simulation_time=0.3, integration_method=m) for m in ("Euler", "RK2", "RK3", "RK4")]
+    out = eng.run(cfgs, ur10)
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+    assert np.abs(out["z"][0] - out["z"][3]).max() > 1e-6
+
+
 def test_ur5_chain(eng, orc):
     from robotic_mpc_amd import robots
 

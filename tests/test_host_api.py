@@ -169,3 +169,15 @@ def test_chunk_bounds_and_buckets():
     cfgs = [config.resolve_config(config.base_params(prediction_horizon=n)) for n in (20, 50, 20, 100, 50)]
     b = d.group_buckets(cfgs)
     assert list(b.values()) == [[0, 2], [1, 4], [3]]
+
+
+def test_plant_integrator_option():
+    """simulation_model.py:13,39-51: integration_method in {Euler, RK2, RK3, RK4}, anything else raises ValueError."""
+    from robotic_mpc_amd import config, packing
+
+    for name, code in (("RK4", 0), ("Euler", 1), ("RK2", 2), ("RK3", 3)):
+        r = config.resolve_config(config.base_params(integration_method=name))
+        assert r["plant_integrator"] == code and packing.pack_params(r)[7] == code
+    assert packing.pack_params(config.resolve_config(config.base_params()))[7] == 0   # simulator.py:85
+    with pytest.raises(ValueError, match="Unknown integration method"):
+        config.resolve_config(config.base_params(integration_method="RK5"))

@@ -6,6 +6,8 @@ closed forms, sympy/numpy kinematics, finite differences, KKT certificates and s
 """
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -341,3 +343,29 @@ def test_rti_and_sqp_agree_in_steady_state(orc, ur10_rb):
     b = orc.run(ur10_rb, orc.make_params(_cfg(solver_options={"nlp_solver_type": "SQP"}, **kw)))
     np.testing.assert_allclose(a["u"][:, -20:], b["u"][:, -20:], atol=5e-2)
     np.testing.assert_allclose(a["z"][:6, -1], b["z"][:6, -1], atol=5e-2)
+
+
+@pytest.mark.parametrize("code,tableau", [
+    (1, ([[0.0]], [1.0])),                                                     # Euler
+    (2, ([[0.0, 0.0], [0.5, 0.0]], [0.0, 1.0])),                               # midpoint (simulation_model.py:98-102)
+    (3, ([[0, 0, 0], [0.5, 0, 0], [-1.0, 2.0, 0]], [1 / 6, 4 / 6, 1 / 6])),    # Kutta's third order (:104-109)
+    (0, ([[0, 0, 0, 0], [0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, 1.0, 0]], [1 / 6, 1 / 3, 1 / 3, 1 / 6])),
+])
+def test_plant_integrators_against_their_butcher_tableaus(orc, code, tableau):
+    """orc_plant_step vs a generic explicit Runge-Kutta step on z' = [qdot; -W(qdot - u)] (simulation_model.py:79-117)
+    and vs the scheme's amplification polynomial R(-w dt) on the velocity."""
+    A, b = np.array(tableau[0], dtype=float), np.array(tableau[1], dtype=float)
+    rng = np.random.default_rng(code)
+    wcv = rng.uniform(20, 300, 6)
+    z, u, dt = rng.normal(size=12), rng.normal(size=6), 0.01
+    f = lambda zz: np.concatenate([zz[6:], -wcv * zz[6:] + wcv * u])
+    ks = []
+    for i in range(len(b)):
+        ks.append(f(z + dt * sum((A[i][j] * ks[j] for j in range(i)), np.zeros(12))))
+    ref = z + dt * sum(bi * ki for bi, ki in zip(b, ks))
+    got = orc.plant_step(code, wcv, dt, z, u)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14)
+    h = -wcv * dt
+    order = {1: 1, 2: 2, 3: 3, 0: 4}[code]
+    R = sum(h ** m / math.factorial(m) for m in range(order + 1))
+    np.testing.assert_allclose(got[6:], R * z[6:] + (1 - R) * u, rtol=0, atol=1e-13)
