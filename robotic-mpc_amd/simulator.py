@@ -23,6 +23,8 @@ of aliasing them (C.7).
 from __future__ import annotations
 
 import copy
+import json
+import os
 import time
 from functools import cached_property
 from itertools import product
@@ -297,14 +299,19 @@ class SimulationManager:
         eng = MpcBatchEngine(dev)
         return lambda cfgs, chain: eng.run(cfgs, chain)
 
-    def run_all(self, return_results=True, distributed: Optional[bool] = None):
+    def run_all(self, return_results=True, distributed: Optional[bool] = None, checkpoint: Optional[str] = None):
         """Run every queued simulation (simulator.py:641-676).
 
         Returns the reference's list of ``{'name','simulator','data','analysis','summary'}``
         dicts, in queue order.  Under ``torch.distributed`` (world_size > 1) every rank must
         call this with the same queue; the full list is returned on rank 0 and ``[]`` elsewhere.
+
+        ``checkpoint`` (extension): path of a results archive (results_io).
+        Simulations already in it -- same name and same config -- are not run again; the archive
+        is rewritten with the union afterwards, so an interrupted grid search resumes.
         """
         from . import distributed as dmod
+        from . import results_io
 
         t_start = time.time()
         sims = [Simulator(**spec["config"]) for spec in self.simulations]
@@ -313,12 +320,38 @@ class SimulationManager:
         resolved = [s.resolved for s in sims]
         runner = self._runner or self._default_runner()
         use_dist = dmod.is_distributed() if distributed is None else distributed
-        records = dmod.run_partitioned(resolved, runner, chain_for, use_dist)
-        self.last_run_info = {"n_sims": len(sims), "wall_s": time.time() - t_start,
-                              "buckets": len({packing.bucket_key(c) for c in resolved}),
+        done: Dict[int, Dict[str, np.ndarray]] = {}
+        arch = None
+        if checkpoint and os.path.exists(checkpoint):
+            arch = results_io.load_archive(checkpoint)
+            have = {str(k): i for i, k in enumerate(arch["keys"])}
+            for i, (sim, spec) in enumerate(zip(sims, self.simulations)):
+                j = have.get(results_io.resume_key(sim.name, spec["config"]))
+                if j is not None:
+                    done[i] = results_io.record_at(arch, j)
+        todo = [i for i in range(len(sims)) if i not in done]
+        new = dmod.run_partitioned([resolved[i] for i in todo], runner, chain_for, use_dist) if todo else []
+        self.last_run_info = {"n_sims": len(sims), "n_resumed": len(done), "wall_s": time.time() - t_start,
+                              "buckets": len({packing.bucket_key(resolved[i]) for i in todo}),
                               "world_size": dmod.world_size() if use_dist else 1}
-        if records is None:  # non-root rank
+        if new is None or (use_dist and dmod.rank() != 0):  # non-root rank
             return [] if return_results else None
+        records = [None] * len(sims)
+        for i, rec in done.items():
+            records[i] = rec
+        for i, rec in zip(todo, new):
+            records[i] = rec
+        if checkpoint and todo:
+            names = [s.name for s in sims]
+            configs = [spec["config"] for spec in self.simulations]
+            recs = list(records)
+            if arch is not None:   # keep what the archive holds beyond this queue: a true union
+                mine = {results_io.resume_key(n, c) for n, c in zip(names, configs)}
+                for j, k in enumerate(arch["keys"]):
+                    if str(k) not in mine:
+                        names.append(str(arch["names"][j])); configs.append(json.loads(str(arch["configs"][j])))
+                        recs.append(results_io.record_at(arch, j))
+            results_io.save_results(checkpoint, names, configs, recs)
         results = []
         for sim, rec in zip(sims, records):
             sim._attach(rec)

@@ -1,5 +1,6 @@
 """Host layer: the reference's SimulationManager / Simulator API (simulator.py:15-716) and
 post-run analysis, exercised without a GPU through an oracle-backed runner."""
+import os
 import warnings
 
 import numpy as np
@@ -181,3 +182,49 @@ def test_plant_integrator_option():
     assert packing.pack_params(config.resolve_config(config.base_params()))[7] == 0   # simulator.py:85
     with pytest.raises(ValueError, match="Unknown integration method"):
         config.resolve_config(config.base_params(integration_method="RK5"))
+
+
+def test_results_archive_round_trip_and_resume(orc, tmp_path):
+    """on-disk result format (plain npz) and resume of a partially completed grid search."""
+    from robotic_mpc_amd import SimulationManager, results_io
+
+    calls = []
+
+    def counting_runner(cfgs, chain):
+        calls.append(len(cfgs))
+        return hp.oracle_runner(cfgs, chain)
+
+    ck = str(tmp_path / "grid.npz")
+    base = _base()
+    m = SimulationManager(base, runner=counting_runner)
+    m.grid_search({"w_qddot": [0.02, 0.05]})
+    first = m.run_all(checkpoint=ck)
+    assert sum(calls) == 2 and os.path.exists(ck) and m.last_run_info["n_resumed"] == 0
+
+    # a larger grid over the same file: only the new combinations run, results identical for the old ones
+    calls.clear()
+    m2 = SimulationManager(base, runner=counting_runner)
+    m2.grid_search({"w_qddot": [0.02, 0.05, 0.1]})
+    second = m2.run_all(checkpoint=ck)
+    assert sum(calls) == 1 and m2.last_run_info["n_resumed"] == 2
+    for a, b in zip(first, second[:2]):
+        assert a["name"] == b["name"]
+        np.testing.assert_array_equal(a["simulator"].simulation_model.z, b["simulator"].simulation_model.z)
+        assert a["summary"] == b["summary"]
+
+    # a changed config under an old name is NOT taken from the archive
+    calls.clear()
+    m3 = SimulationManager({**base, "px_ref": 0.45}, runner=counting_runner)
+    m3.grid_search({"w_qddot": [0.02]})
+    m3.run_all(checkpoint=str(tmp_path / "grid.npz"))
+    assert sum(calls) == 1
+
+    # the archive is the union of everything run so far and alone reproduces run_all's dicts
+    loaded = results_io.load_results(ck)
+    assert len(loaded) == 4 and {r["name"] for r in second} <= {r["name"] for r in loaded}
+    by_name = {r["name"]: r for r in loaded if r["simulator"].px_ref == base["px_ref"]}
+    assert by_name[first[0]["name"]]["summary"] == first[0]["summary"]
+    arch = results_io.load_archive(ck)
+    assert set(("names", "configs", "keys", "nsim", "z", "u", "status", "residuals")) <= set(arch)
+    r0 = results_io.load_results(ck)[0]
+    assert r0["summary"]["num_failures"] >= 0 and r0["simulator"].simulation_model.z.shape[0] == 12
