@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--solver", default="SQP_RTI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (rehearsal of the "
+                    "multi-rank control flow on a box with fewer GPUs than ranks: tensors are gathered via the host)")
     args = ap.parse_args()
 
     import torch
@@ -133,8 +135,13 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU (torch.distributed.run), WORLD_SIZE={world}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":   # rehearsal: ranks may share a GPU
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
 
@@ -156,10 +163,10 @@ def main():
         if world > 1 and not args.no_gather:
             try:
                 for name in ("z", "u", "status", "cost"):
-                    t = bufs[name]
+                    t = bufs[name] if args.backend == "nccl" else bufs[name].cpu()
                     lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
                     dist.gather(t, lst, dst=0)
-                gather_note = "rccl gather of z,u,status,cost to rank 0"
+                gather_note = ("rccl" if args.backend == "nccl" else "gloo (via host)") + " gather of z,u,status,cost to rank 0"
             except Exception as e:  # keep the measurement alive if the collective is unavailable
                 gather_note = f"gather failed: {e!r}"
 
@@ -176,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         kernel_ms.append(eng.kernel_ms())
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
