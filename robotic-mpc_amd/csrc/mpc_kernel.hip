@@ -216,8 +216,11 @@ struct DevExec {
     __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
 };
 
+#ifndef MPCB_WPE
+#define MPCB_WPE 1
+#endif
 template <int NWV>
-__global__ __launch_bounds__(WAVE *NWV) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+__global__ __launch_bounds__(WAVE *NWV, MPCB_WPE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
                                                            double *ws_base, size_t ws_stride, Outputs out, int step0,
                                                            int step1, int pool_doubles)
 {

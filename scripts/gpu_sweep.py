@@ -6,7 +6,7 @@ import numpy as np
 import bench
 from robotic_mpc_amd import engine, robots
 
-eng = engine.MpcBatchEngine(0)
+eng = engine.MpcBatchEngine(0, lib_path=os.environ.get("MPCB_LIB"))
 ch = robots.builtin_chain("ur10")
 print("kernel", eng.kernel_info(), flush=True)
 cases = [(256, 20, "SQP_RTI", 6.0), (256, 50, "SQP_RTI", 6.0), (256, 100, "SQP_RTI", 6.0), (256, 200, "SQP_RTI", 3.0),
