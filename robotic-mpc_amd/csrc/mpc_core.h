@@ -1,13 +1,19 @@
 // mpc_core.h -- the batched MPC rollout engine, single source for the gfx950 kernel.
 //
-// One wavefront = one closed-loop simulation (Simulator.run, simulator.py:199-241).
-// The code is written as bulk-synchronous phases `ex.par([&](int lane){...})`: inside a
-// phase a lane only reads data produced by earlier phases and writes entries no other lane
-// reads in that phase; `par` ends with a wavefront-scope fence.  On the GPU `Ex` is DevExec
-// (mpc_kernel.hip: lane = threadIdx.x; the fence is compiler-only because a single wave
-// executes its LDS/VMEM instructions in order).  tests/emu instantiates the same template
-// with a host executor that loops over the 64 lanes -- a debugging aid for a container
-// without a GPU, never part of the product library.
+// One workgroup of NW wavefronts (NT = 64*NW lanes) = one closed-loop simulation (Simulator.run,
+// simulator.py:199-241).  The code is written against a small executor `Ex`:
+//   ex.par(f)             bulk-synchronous phase on all NT lanes; a lane only reads what earlier phases
+//                         produced and writes entries nobody reads in that phase; ends with the barrier
+//   ex.seq(f)             one step of a stage-by-stage recursion: wavefront 0 only, wave-local fence
+//   ex.overlap3(fg,mid,bg) one WINDOW: the recursion `fg` on wavefront 0, a follower `mid` on wavefront 1
+//                         (its own wave-local `ex.sub` phases), barrier-free background work
+//                         `bg(lane, lanes)` -- chunk copies -- on the rest; one barrier at the end
+//   ex.post / ex.await    progress counter (LDS) from the recursion to its followers
+//   ex.share/gather/shl6/shr6  hand a value from lane to lane between seq phases (registers)
+//   ex.put_* / get_*      reductions over the simulation's lanes;  ex.uni(v): wave-uniform value
+// On the GPU `Ex` is DevExec<NW> (mpc_kernel.hip).  tests/emu instantiates the same template with
+// a host executor that loops over the lanes and runs the roles one after the other -- a
+// debugging aid for a container without a GPU, never part of the product library.
 //
 // Algorithm (what acados + HPIPM do behind trajectory_optimizer.py:183-186):
 //   SQP_RTI / SQP with Gauss-Newton Hessian  ->  OCP-QP in delta form  ->  Mehrotra
@@ -18,19 +24,14 @@
 // coupling is the rank-5 task term 50*dt*G'G.  The 6x6 R~ is factorised redundantly by all
 // lanes (LDL'), the 18 right-hand sides (12 columns of S~, 6 of I) are solved one per lane.
 //
-// Lanes: a simulation is owned by NT = 64*NW lanes (NW wavefronts of one workgroup).  `ex.par`
-// phases run on all NT lanes and end with a workgroup barrier -- the chunk I/O and every
-// chunk-parallel phase; `ex.seq` phases run on wavefront 0 only (the stage-by-stage recursions,
-// whose phases are separated by a wave-local fence, no s_barrier); `ex.join()` is the barrier
-// that hands wave 0's results back to everybody.
-//
 // Memory: every pass streams CHUNKS of consecutive stage records HBM -> LDS -> HBM
-// (mpc_layout.h).  One IPM iteration is five passes: factorisation sweep, forward sweep +
+// (mpc_layout.h); the three sweeps keep two chunks in flight so that the copies run in the shadow
+// of the recursion.  One IPM iteration is five passes: factorisation sweep, predictor sweep +
 // step lengths, corrector + backward solve, forward sweep + step lengths, update + residuals.
 #pragma once
 #include "mpc_kin.h"
 
-// 16-way manual unrolling with individually named registers (see Engine::load_rect)
+// 16-way manual unrolling with individually named registers (see Engine::copy_lanes)
 #define MPC_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 namespace mpcb {

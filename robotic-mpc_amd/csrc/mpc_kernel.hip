@@ -1,9 +1,9 @@
 // mpc_kernel.hip -- gfx950 kernel + C ABI (include/mpcbatch.h) of the batched MPC engine.
 //
-// Launch geometry: one 64-thread workgroup (= one wavefront) per simulation instance, grid =
-// batch.  A wave is never split across phases, so the phase separator is a wavefront-scope
-// fence + wave barrier: no s_barrier, no forced vmcnt(0) -- a single wave issues its LDS and
-// vector-memory instructions in order, which is all the bulk-synchronous phases need.
+// Launch geometry: one workgroup of NWV wavefronts (1, 2, 4 or 8; mpcb_setup picks it from the
+// batch) per simulation instance, grid = batch.  DevExec<NWV> below is the device executor of the
+// engine template (mpc_core.h): workgroup barriers between bulk-synchronous phases, wave-local
+// fences inside a recursion, role-split windows (overlap3), DPP/readlane cross-lane helpers.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -25,7 +25,7 @@ static_assert(sizeof(mpcb_problem) == sizeof(Problem), "ABI struct mismatch");
 static_assert(sizeof(mpcb_result) == sizeof(Outputs), "ABI struct mismatch");
 static_assert(sizeof(Robot) == MPCB_NROBOT * sizeof(double), "robot layout");
 
-// LDS of the workgroup (= one wavefront = one simulation): fixed working set + chunk pool.
+// LDS of the workgroup (= one simulation): fixed working set + chunk pool.
 __shared__ __attribute__((aligned(16))) Smem g_sm;
 extern __shared__ __attribute__((aligned(16))) double g_pool[];
 

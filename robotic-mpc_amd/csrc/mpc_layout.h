@@ -1,10 +1,10 @@
 // mpc_layout.h -- data layout of the batched MPC rollout engine (gfx950).
 //
-// One wavefront (64 lanes) owns one simulation instance.  All per-instance solver state
+// One workgroup (1-8 wavefronts) owns one simulation instance.  All per-instance solver state
 // lives in an HBM workspace, STAGE-MAJOR, split into five record groups so that every pass of
 // the solver streams whole contiguous stage records:
 //     G1 ITER  iterate + QP iterate      G2 LINR  linearisation + Newton right-hand sides
-//     G3 STEP  residuals + Newton step   G4 FACT  Riccati factor (K, R^-1, h_u, p, P)
+//     G3 STEP  residuals + Newton step   G4 FACT  Riccati factor (K, R^-1, h_u, p, w, P)
 //     G5 SQPX  SQP-only extras (NLP multipliers, trial point, merit weights)
 // A pass copies a CHUNK of consecutive stages HBM -> LDS in one coalesced burst (16 B per
 // lane, all loads in flight together), works on the chunk entirely in LDS -- the sequential
@@ -144,7 +144,7 @@ MPC_HD Ws ws_carve(double *base, int N)
     return w;
 }
 
-// Static LDS working set of one wavefront; the chunk pool follows it (dynamic LDS).
+// Static LDS working set of one simulation (workgroup); the chunk pool follows it (dynamic LDS).
 // Every array is 16-byte aligned: the compiler merges neighbouring doubles into ds_read/write_b128,
 // and a b128 DS access off its 16-byte alignment is replayed at ~64 cycles (MI355X_MICROARCH.md, LDS).
 struct Smem {
