@@ -85,10 +85,6 @@ struct DevExec {
             wave_fence();
         }
     }
-    __device__ __forceinline__ void join()
-    {
-        if (NWV > 1) __syncthreads();
-    }
     // A stage-by-stage recursion (`fg`, made of seq phases, wavefront 0) with the other wavefronts
     // doing barrier-free background work `bg(lane, lanes)` (chunk copies for the neighbouring
     // chunks) in its shadow; ends with the workgroup barrier.  With one wavefront per simulation

@@ -51,7 +51,6 @@ constexpr int O_GAM = 60;  // Gamma = lam/t (12)
 constexpr int O_GT = 72;   // condensed gradient of the Newton system (18)
 constexpr int O_RB = 90;   // dynamics residual of the QP iterate (12)
 constexpr int W2_LIN = 60;   // [R..GV]: what a linearisation produces
-constexpr int W2_USED = 102;  // [R..RB]
 // ---- G3 STEP ----------------------------------------------------------------------
 constexpr int W3 = 144;
 constexpr int O_RG = 0, O_RD = 18, O_RM = 42;  // residuals g (18), d (24), m (24)
@@ -156,13 +155,9 @@ struct Smem {
     alignas(16) double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)
     alignas(16) double pv[2][12];
     alignas(16) double Rt[36];      // R~ = H_uu + Gamma_u + B'MB
-    alignas(16) double St[72];      // S~ = H_ux + B'MA           (6x12)
     alignas(16) double St2[2][72];  // S~ double buffer of the factorisation sweep (stage k read, k-1 written)
     alignas(16) double Kf[72];      // R~^-1 S~
-    alignas(16) double mt[12];      // p_{k+1} + P_{k+1} rb_k
-    alignas(16) double hx[12];      // h_x
     alignas(16) double dx[2][12];
-    alignas(16) double du[6];
     alignas(16) double red[8][NWV_MAX];   // one partial per wavefront (Ex::put_* / get_*)
     alignas(16) double xhat[12];    // current plant state (feedback, simulator.py:206)
     alignas(16) double u0[6];

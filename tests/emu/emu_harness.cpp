@@ -44,7 +44,6 @@ struct HostExec {
     {
         for (int l = 0; l < WAVE; l++) f(l);
     }
-    void join() {}
     template <class FG, class BG>
     void overlap(FG &&fg, BG &&bg)
     {
