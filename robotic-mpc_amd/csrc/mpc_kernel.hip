@@ -379,7 +379,7 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         int wpc = (p->batch + h->num_cus - 1) / h->num_cus;
         if (wpc > 2) wpc = 2;
         if (const char *e2 = getenv("MPCB_SIMS_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 8) wpc = v; }
-        const int lds_total = 160 * 1024, fixed = (int)sizeof(Smem) + 1024;
+        const int lds_total = 160 * 1024, fixed = (int)sizeof(Smem) + 64;
         int bytes = lds_total / (wpc < 1 ? 1 : wpc) - fixed;
         if (bytes > POOL_DEFAULT_DOUBLES * 8) bytes = POOL_DEFAULT_DOUBLES * 8;
         if (bytes < POOL_MIN_DOUBLES * 8) bytes = POOL_MIN_DOUBLES * 8;

@@ -166,6 +166,6 @@ struct Smem {
 
 // Chunk pool sizes (doubles).  The widest pass needs ~500 doubles per stage (+1 halo stage).
 constexpr int POOL_MIN_DOUBLES = 2048;
-constexpr int POOL_DEFAULT_DOUBLES = 16384;  // 128 KiB: one wave per CU (batch <= 256 per GPU)
+constexpr int POOL_DEFAULT_DOUBLES = 19456;  // 152 KiB cap: one simulation per CU (batch <= 256 per GPU) gets all the LDS left beside Smem
 
 }  // namespace mpcb
