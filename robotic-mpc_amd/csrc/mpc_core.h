@@ -147,11 +147,17 @@ struct Engine {
     MPC_HD void copy_lanes(double *l, double *g, int k_lo, int k_hi, int lane)
     {
         static_assert(W % 2 == 0 && C0 % 2 == 0 && LDG % 2 == 0 && LDL % 2 == 0, "16-byte granularity");
+        if constexpr (!(W == LDG && W == LDL) && W > 2 * WAVE) {
+            // partial rows wider than one wavefront of 16-byte items: column pieces of 128 doubles
+            copy_lanes<2 * WAVE, C0, LDG, LDL, LOAD, NL>(l, g, k_lo, k_hi, lane);
+            copy_lanes<W - 2 * WAVE, C0 + 2 * WAVE, LDG, LDL, LOAD, NL>(l + 2 * WAVE, g, k_lo, k_hi, lane);
+            return;
+        }
         constexpr int W2h = W / 2;
         constexpr int SH = W2h <= 1 ? 0 : (W2h <= 2 ? 1 : (W2h <= 4 ? 2 : (W2h <= 8 ? 3 : (W2h <= 16 ? 4 : (W2h <= 32 ? 5 : (W2h <= 64 ? 6 : (W2h <= 128 ? 7 : 8)))))));
         constexpr int PITCH = 1 << SH;             // >= W2h
         constexpr bool FLAT = (W == LDG && W == LDL);   // whole rows: one contiguous span on both sides
-        static_assert(FLAT || (PITCH >= W2h && PITCH <= WAVE), "partial rows wider than a wavefront are not needed");
+        static_assert(FLAT || W > 2 * WAVE || (PITCH >= W2h && PITCH <= WAVE), "one partial row fits a wavefront of 16-byte items");
         static_assert(NL % WAVE == 0, "whole wavefronts");
         constexpr int RPI = FLAT ? 1 : NL / PITCH;  // rows covered by one instruction group
         // the bounds are the same in every lane; telling the compiler so keeps the copy loops scalar
@@ -441,7 +447,6 @@ struct Engine {
                 if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, c.w.G3, lo, hi, lane);
                 copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, c.w.G2, k0, k1, lane);
             });
-            PROF_T0(tx);
             ex.par([&](int lane) {
                 const int rows = hi - lo + 1;
                 double ncl = 0.0;
@@ -481,8 +486,6 @@ struct Engine {
                 ex.put_sum(sm.red[5], lane, ncl);
             });
             if (mode == 0) nc += ex.get_sum(sm.red[5]);
-            PROF_ADD(PF_X1, tx);
-            PROF_T0(ty);
             // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -501,8 +504,6 @@ struct Engine {
                     r2[O_Y + i] = P.w_task[i] * v;
                 }
             });
-            PROF_ADD(PF_X2, ty);
-            PROF_T0(tz);
             // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg.  Four kinds of rows -- u, q, v
             // components of the stationarity residual and the dynamics residual -- each have their own
             // formulas: a wavefront works on ONE kind at a time, so no lane diverges from its neighbours.
@@ -584,7 +585,6 @@ struct Engine {
             nd = fmax(nd, ex.get_max(sm.red[2]));
             nm = fmax(nm, ex.get_max(sm.red[3]));
             smu += ex.get_sum(sm.red[4]);
-            PROF_ADD(PF_X3, tz);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<78, O_QW, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, lane);
@@ -695,12 +695,12 @@ struct Engine {
                         if (lane < NX) {
                             const double v = gt[6 + lane];
                             pr.at(lane) = v; ex.share(sm.pv[vcur], lane, v);
-                            fac[O_PV + lane] = v; fac[O_WV + lane] = 0.0;
+                            fac[O_PV + lane] = v; fac[O_WV + lane] = 0.0; fac[O_E + lane] = 0.0;
                             const int j = lane % 6;
                             D2 c2; c2.x = P.a12[j]; c2.y = P.a22[j];
                             ab.at(lane) = c2;
                         }
-                        if (lane < NU) fac[O_HU + lane] = 0.0;
+                        if (lane < NU) fac[O_VH + lane] = 0.0;
                     });
                     continue;
                 }
@@ -738,12 +738,14 @@ struct Engine {
                         pr.at(lane) = pj; ex.share(sm.pv[vnxt], lane, pj);
                         fac[O_PV + j] = pj;
                         fac[O_WV + j] = w;
-                        if (j < 6) {
-                            double v = hu[0];
+                        // what the forward sweep needs of h_u: R~^-1 h_u and e = rb - B R~^-1 h_u
+                        const int i6 = j < 6 ? j : j - 6;
+                        double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-                            for (int m = 1; m < 6; m++) v = j == m ? hu[m] : v;
-                            fac[O_HU + j] = v;
-                        }
+                        for (int m = 0; m < 6; m += 2) { v0 += fac[O_RI + i6 * 6 + m] * hu[m]; v1 += fac[O_RI + i6 * 6 + m + 1] * hu[m + 1]; }
+                        const double vh = v0 + v1;
+                        if (j < 6) fac[O_VH + j] = vh;
+                        fac[O_E + j] = rbv[j] - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
                     }
                 });
                 vcur = vnxt;
@@ -761,6 +763,7 @@ struct Engine {
             if (!has_mat && ci == 0) break;
             PROF_T0(ts);
             ex.overlap3([&]() {
+            PROF_T0(tx1);
             if (has_mat)
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
@@ -872,21 +875,24 @@ struct Engine {
                 });
                 sb ^= 1;
             }
+            PROF_ADD(PF_X1, tx1);
             }, [&]() {
                 // wavefront 1: vector recursion of the previous chunk, then its h_u | p | w columns go home
                 if (ci > 0) {
                     vec_sweep(ci - 1);
                     ex.sub([&](int lane) {
-                        copy_lanes<30, O_HU, W4, W4, false, WAVE>(vf_of(ci - 1) + O_HU, c.w.G4, pk0, pk1, lane);
+                        copy_lanes<30, O_VH, W4, W4, false, WAVE>(vf_of(ci - 1) + O_VH, c.w.G4, pk0, pk1, lane);   // R~^-1 h_u | e | p
+                        copy_lanes<12, O_WV, W4, W4, false, WAVE>(vf_of(ci - 1) + O_WV, c.w.G4, pk0, pk1, lane);
                     });
                 }
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (has_mat && nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), c.w.G2, nkl, nk1, lane);
                 if (ci > 0) {
-                    copy_lanes<O_HU, 0, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
+                    copy_lanes<72, O_K, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
                     copy_lanes<72, O_PM, W4, W4, false, NL>(vf_of(ci - 1) + O_PM, c.w.G4, pk0, pk1, lane);
                     copy_lanes<72, O_PM + 72, W4, W4, false, NL>(vf_of(ci - 1) + O_PM + 72, c.w.G4, pk0, pk1, lane);
+                    copy_lanes<36, O_RI, W4, W4, false, NL>(vf_of(ci - 1) + O_RI, c.w.G4, pk0, pk1, lane);
                 }
             });
             PROF_ADD(PF_SEQ_FACT, ts);
@@ -912,9 +918,10 @@ struct Engine {
         constexpr int L3 = 90;                   // RG 0 | RD 18 | DLAM 42 | DT 66  (G3 without RM and the step)
         constexpr int C_DLAM = 42, C_DT = 66;
         constexpr int WGR = 30;                  // GT 0 (rebuilt in place) | RB 18
-        constexpr int WK = 72, WW = 12;          // Kfb ; w = P_{k+1} rb_k
+        constexpr int WK = 72, WW = 48;          // Kfb ; w = P_{k+1} rb_k (12) | R~^-1 (36)  (adjacent in G4)
         constexpr int WC = 12;                   // c_k: the part of p_k that does not depend on p_{k+1}
-        constexpr int WRM = 24, WHP = 18;        // outputs: RM ; h_u (6) | p (12)
+        constexpr int WRM = 24, WHP = 30;        // outputs: RM ; R~^-1 h_u (6) | e (12) | p (12)  (adjacent in G4)
+        constexpr int C_PV = 18;
         constexpr int PER = WLT + L3 + WGR + WK + WW + WC + WRM + WHP;
         const int CH = chunk_len(2 * PER, 0);
         typename Ex::template PerLane<D2> ab;       // lanes < 12: (a12, a22) of the lane's joint
@@ -998,6 +1005,7 @@ struct Engine {
             });
             PROF_T0(ts);
             ex.overlap([&]() {
+            PROF_T0(tx2);
             for (int k = k1; k >= k0; k--) {
                 const double *gt = vgr + (size_t)(k - k0) * WGR;
                 const double *cv = vc + (size_t)(k - k0) * WC;
@@ -1009,7 +1017,8 @@ struct Engine {
                         if (lane < NX) {
                             const double v = gt[6 + lane];
                             pr.at(lane) = v; ex.share(sm.pv[cur], lane, v);
-                            hp[6 + lane] = v;
+                            hp[C_PV + lane] = v;
+                            hp[6 + lane] = 0.0;
                         }
                         if (lane < NU) hp[lane] = 0.0;
                     });
@@ -1034,11 +1043,12 @@ struct Engine {
                         const double at = j < 6 ? mine : c2.x * oq + c2.y * mine;
                         const double pj = cv[j] + (at - (acc0 + acc1));
                         pr.at(lane) = pj; ex.share(sm.pv[nxt], lane, pj);
-                        hp[6 + j] = pj;
+                        hp[C_PV + j] = pj;
                     }
                 });
                 cur = nxt;
             }
+            PROF_ADD(PF_X2, tx2);
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk1 >= 0) {
@@ -1051,27 +1061,39 @@ struct Engine {
                 }
                 if (k1 < Nl) {
                     copy_lanes<WRM, O_RM, W3, WRM, false, NL>(prm, c.w.G3, k1 + 1, k1 + CH, lane);
-                    copy_lanes<WHP, O_HU, W4, WHP, false, NL>(php, c.w.G4, k1 + 1, k1 + CH, lane);
+                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(php, c.w.G4, k1 + 1, k1 + CH, lane);
                 }
             });
             PROF_ADD(PF_SEQ_BWD, ts);
-            // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k)
+            // chunk-parallel: h_u,k = gt_u + B'(p_{k+1} + w_k); the forward sweep wants it as R~^-1 h_u and
+            // e = rb - B R~^-1 h_u (lane <-> (stage, state component j); h_u is formed redundantly)
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 6; e += NT) {
-                    const int s = e / 6, i = e - s * 6, k = k0 + s;
+                for (int e = lane; e < rows * NX; e += NT) {
+                    const int s = e / NX, j = e - s * NX, k = k0 + s;
                     if (k >= Nl) continue;
-                    const double *gt = vgr + (size_t)s * WGR, *w = vw + (size_t)s * WW;
+                    const double *gt = vgr + (size_t)s * WGR, *w = vw + (size_t)s * WW, *ri = w + 12;
                     // p_{k+1}: next row of this chunk, or the lowest row of the previous chunk (other buffer)
-                    const double *pn = (s + 1 < rows ? ohp + (size_t)(s + 1) * WHP : php) + 6;
-                    ohp[(size_t)s * WHP + i] = gt[i] + P.b1[i] * (pn[i] + w[i]) + P.b2[i] * (pn[6 + i] + w[6 + i]);
+                    const double *pn = (s + 1 < rows ? ohp + (size_t)(s + 1) * WHP : php) + C_PV;
+                    const int i6 = j < 6 ? j : j - 6;
+                    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 6; m += 2) {
+                        const double h0 = gt[m] + P.b1[m] * (pn[m] + w[m]) + P.b2[m] * (pn[6 + m] + w[6 + m]);
+                        const double h1 = gt[m + 1] + P.b1[m + 1] * (pn[m + 1] + w[m + 1]) + P.b2[m + 1] * (pn[7 + m] + w[7 + m]);
+                        v0 += ri[i6 * 6 + m] * h0; v1 += ri[i6 * 6 + m + 1] * h1;
+                    }
+                    const double vh = v0 + v1;
+                    double *hp = ohp + (size_t)s * WHP;
+                    if (j < 6) hp[j] = vh;
+                    hp[6 + j] = gt[18 + j] - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
                 }
             });
             if (k0 == 0) {
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
                     copy_lanes<WRM, O_RM, W3, WRM, false, NL>(orm, c.w.G3, k0, k1, lane);
-                    copy_lanes<WHP, O_HU, W4, WHP, false, NL>(ohp, c.w.G4, k0, k1, lane);
+                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(ohp, c.w.G4, k0, k1, lane);
                 });
             }
         }
@@ -1082,7 +1104,7 @@ struct Engine {
     // dt, dlam from the primal step (HPIPM compute_lam_t), the largest feasible step and the
     // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.  Only the state recursion
     // dx_{k+1} = A dx_k - B (Kfb dx_k + Rinv h_u) + rb_k is sequential (one phase per stage);
-    // Rinv h_u before and du_k, dpi_{k-1} = P_k dx_k + p_k after it are chunk-parallel.
+    // Rinv h_u and e = rb - B Rinv h_u come with the factor (written by whoever produced h_u).
     template <bool AFFINE>
     MPC_PASS double forward_step_pass(double *S)
     {
@@ -1090,15 +1112,15 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
-        constexpr int WRB = 12, WLT = 48, WR = 48, WO = 78, WH = 18;
+        constexpr int WLT = 48, WR = 48, WO = 78;
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
-        // K, R~^-1, h_u (no p, no P) and leaves only dlam, dt behind for the corrector
-        constexpr int LF = AFFINE ? O_PV : W4;
+        // K, R~^-1 h_u, e (no p, no P) and leaves only dlam, dt behind for the corrector
+        constexpr int LF = AFFINE ? W4_AFF : W4_FWD;
         // Three roles per window ci (Ex::overlap3), two chunks in flight:
         //   wavefront 0   state recursion dx of chunk ci; publishes its progress (sm.prog)
         //   wavefront 1   follows it in blocks of BLK stages: du, dpi, dlam, dt, step length, centering sums
         //   wavefronts 2+ fetch the inputs of chunk ci+1, write the step of chunk ci-1 back
-        constexpr int PER = LF + WRB + WLT + WR + WO + WH;
+        constexpr int PER = LF + WLT + WR + WO;
 #ifndef MPCB_FWD_BLK
 #define MPCB_FWD_BLK 4
 #endif
@@ -1122,12 +1144,11 @@ struct Engine {
         });
         int cur = 0;
         {
-            double *q4 = pool, *qrb = q4 + (size_t)CH * LF, *qlt = qrb + (size_t)CH * WRB, *qr = qlt + (size_t)CH * WLT;
+            double *q4 = pool, *qlt = q4 + (size_t)CH * LF, *qr = qlt + (size_t)CH * WLT;
             const int e1 = imin(CH - 1, Nl);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<LF, 0, W4, LF, true, NL>(q4, c.w.G4, 0, e1, lane);
-                copy_lanes<WRB, O_RB, W2, WRB, true, NL>(qrb, c.w.G2, 0, e1, lane);
                 copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(qlt, c.w.G1, 0, e1, lane);
                 copy_lanes<WR, O_RD, W3, WR, true, NL>(qr, c.w.G3, 0, e1, lane);
             });
@@ -1135,37 +1156,19 @@ struct Engine {
         for (int ci = 0; ci < NCH; ci++) {
             const int k0 = ci * CH, k1 = imin(k0 + CH - 1, Nl);
             double *v4 = pool + (size_t)(ci & 1) * CH * PER;   // rows k0..k1, G4
-            double *vrb = v4 + (size_t)CH * LF;       // RB
-            double *vlt = vrb + (size_t)CH * WRB;     // QLAM | QT
+            double *vlt = v4 + (size_t)CH * LF;       // QLAM | QT
             double *vr = vlt + (size_t)CH * WLT;      // RD | RM
             double *vo = vr + (size_t)CH * WR;        // DW | DPI | DLAM | DT  (out)
-            double *vh = vo + (size_t)CH * WO;        // Rinv h_u (6) | e (12)
             // the other buffer: inputs of the next chunk, output of the previous one
-            double *n4 = pool + (size_t)((ci + 1) & 1) * CH * PER, *nrb = n4 + (size_t)CH * LF, *nlt = nrb + (size_t)CH * WRB,
+            double *n4 = pool + (size_t)((ci + 1) & 1) * CH * PER, *nlt = n4 + (size_t)CH * LF,
                    *nr = nlt + (size_t)CH * WLT, *po = nr + (size_t)CH * WR;
             const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
-            // chunk-parallel: R~^-1 h_u (6) and e = rb - B R~^-1 h_u (12), the part of dx_{k+1} that
-            // does not depend on dx_k
-            ex.par([&](int lane) {
-                const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * 6; e += NT) {
-                    const int s = e / 6, i = e - s * 6;
-                    const double *fac = v4 + (size_t)s * LF;
-                    double v = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) v += fac[O_RI + i * 6 + m] * fac[O_HU + m];
-                    double *h = vh + (size_t)s * WH;
-                    h[i] = v;
-                    h[6 + i] = vrb[(size_t)s * WRB + i] - P.b1[i] * v;
-                    h[12 + i] = vrb[(size_t)s * WRB + 6 + i] - P.b2[i] * v;
-                }
-            });
             PROF_T0(ts);
             ex.overlap3([&]() {
+            PROF_T0(tx3);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
-                const double *h = vh + (size_t)(k - k0) * WH;
                 double *o = vo + (size_t)(k - k0) * WO;
                 // dx_{k+1} = e_k + A dx_k - B K dx_k: dx_k travels lane to lane in registers
                 ex.seq([&](int lane) {
@@ -1186,7 +1189,7 @@ struct Engine {
                             }
                             const double kd = s0 + s1;
                             const D2 a = ab.at(lane), b = bb.at(lane);
-                            const double v = h[6 + lane] + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                            const double v = fac[O_E + lane] + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
                             dxr.at(lane) = v; ex.share(sm.dx[nxt], lane, v);
                         }
                     }
@@ -1194,6 +1197,7 @@ struct Engine {
                 });
                 if (k < Nl) cur = nxt;
             }
+            PROF_ADD(PF_X3, tx3);
             }, [&]() {
                 // wavefront 1 follows the recursion block by block: du_k = -(R~^-1 h_u + K dx_k), then
                 // dlam, dt (HPIPM compute_lam_t), largest feasible step, centering sums -- one phase,
@@ -1213,7 +1217,7 @@ struct Engine {
                             if (j < 6) {
                                 dv = 0.0;
                                 if (k < Nl) {
-                                    double s0 = vh[(size_t)(k - k0) * WH + j], s1 = 0.0;
+                                    double s0 = fac[O_VH + j], s1 = 0.0;
 #pragma unroll
                                     for (int i = 0; i < NX; i += 2) { s0 += fac[O_K + j * 12 + i] * dxk[i]; s1 += fac[O_K + j * 12 + i + 1] * dxk[i + 1]; }
                                     dv = -(s0 + s1);
@@ -1256,7 +1260,6 @@ struct Engine {
                 constexpr int NL = decltype(nl)::value;
                 if (nk0 <= Nl) {
                     copy_lanes<LF, 0, W4, LF, true, NL>(n4, c.w.G4, nk0, nk1, lane);
-                    copy_lanes<WRB, O_RB, W2, WRB, true, NL>(nrb, c.w.G2, nk0, nk1, lane);
                     copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
                     copy_lanes<WR, O_RD, W3, WR, true, NL>(nr, c.w.G3, nk0, nk1, lane);
                 }

@@ -4,7 +4,7 @@
 // lives in an HBM workspace, STAGE-MAJOR, split into five record groups so that every pass of
 // the solver streams whole contiguous stage records:
 //     G1 ITER  iterate + QP iterate      G2 LINR  linearisation + Newton right-hand sides
-//     G3 STEP  residuals + Newton step   G4 FACT  Riccati factor (K, R^-1, h_u, p, w, P)
+//     G3 STEP  residuals + Newton step   G4 FACT  Riccati factor (K, R^-1 h_u, e, p, P, w, R^-1)
 //     G5 SQPX  SQP-only extras (NLP multipliers, trial point, merit weights)
 // A pass copies a CHUNK of consecutive stages HBM -> LDS in one coalesced burst (16 B per
 // lane, all loads in flight together), works on the chunk entirely in LDS -- the sequential
@@ -58,13 +58,18 @@ constexpr int O_DW = 66;    // Newton step [du; dq; dqdot] (18)
 constexpr int O_DPI = 84;   // step of the multiplier of dynamics k-1 -> k (12)   (note the shift)
 constexpr int O_DLAM = 96, O_DT = 120;
 // ---- G4 FACT ----------------------------------------------------------------------
-constexpr int W4 = 282;
+// Ordered by consumer: the forward sweeps read a prefix ([K..E] predictor, [K..P] final sweep), the
+// corrector reads K and the tail [w, R~^-1].
+constexpr int W4 = 294;
 constexpr int O_K = 0;      // Kfb = R~^-1 S~ (6x12)
-constexpr int O_RI = 72;    // R~^-1 (6x6)
-constexpr int O_HU = 108;   // h_u (6)
-constexpr int O_PV = 114;   // p_k (12)
-constexpr int O_WV = 126;   // w_k = P_{k+1} rb_k (12): reused by the corrector's backward solve
-constexpr int O_PM = 138;   // P_k (12x12)
+constexpr int O_VH = 72;    // R~^-1 h_u (6)
+constexpr int O_E = 78;     // e = rb - B R~^-1 h_u (12): the part of dx_{k+1} that does not depend on dx_k
+constexpr int O_PV = 90;    // p_k (12)
+constexpr int O_PM = 102;   // P_k (12x12)
+constexpr int O_WV = 246;   // w_k = P_{k+1} rb_k (12): reused by the corrector's backward solve
+constexpr int O_RI = 258;   // R~^-1 (6x6)
+constexpr int W4_AFF = O_PV;   // what the predictor sweep loads
+constexpr int W4_FWD = O_WV;   // what the final forward sweep loads
 // ---- G5 SQPX ----------------------------------------------------------------------
 constexpr int W5 = 116;
 constexpr int O_NPI = 0, O_NLAM = 12, O_NT = 36, O_TX = 60, O_TU = 72, O_MW = 78;  // MW: dyn 12 + ineq 24
