@@ -616,6 +616,7 @@ struct Engine {
         double mqq, mqv, mvq, mvv;   // P_{k+1} block (a,b)
         double qqq, qqv, qvq, qvv;   // A' P_{k+1} A block (a,b)
         int a, b;
+        int oqq, oqv, ovv;           // packed offsets (tri) of the block's qq, qv, vv entries
     };
 
     MPC_PASS void fact_pass()
@@ -625,12 +626,13 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
-        const int CH = chunk_len(3 * WR + 2 * W4, 3 * WR);
+        const int CH = chunk_len(2 * (WR + W4), 2 * WR);
         typename Ex::template PerLane<FactLane> fl;
         ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
             const int a = lane < 36 ? lane / 6 : 0, b = lane < 36 ? lane % 6 : 0;
             f.a = a; f.b = b;
+            f.oqq = tri(imin(a, b), imax(a, b)); f.oqv = tri(a, 6 + b); f.ovv = tri(6 + imin(a, b), 6 + imax(a, b));
             f.b1a = P.b1[a]; f.b2a = P.b2[a]; f.b1b = P.b1[b]; f.b2b = P.b2[b];
             f.a12a = P.a12[a]; f.a22a = P.a22[a]; f.a12b = P.a12[b]; f.a22b = P.a22[b];
             const double c2 = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
@@ -658,18 +660,14 @@ struct Engine {
             (void)lane;
         };
         // Three roles per window (Ex::overlap3), chunk index ci counts down the horizon:
-        //   wavefront 0   matrix recursion (P, K, R~^-1) of chunk ci
-        //   wavefront 1   vector recursion (w, h_u, p) of chunk ci-1 on the finished matrices, then
-        //                 writes those columns back
-        //   wavefronts 2+ fetch the inputs of chunk ci+1, write the matrix columns of chunk ci-1 back
-        // Inputs are triple-buffered (chunk ci-1 is still read while ci+1 arrives), the factor is
-        // double-buffered; the lowest-stage P of every chunk is kept in sm.Pseam[ci % 3] because the
-        // factor buffer of chunk ci-2 is being overwritten when the vector recursion of ci-1 needs it.
+        //   wavefront 0   matrix recursion (P, K, R~^-1) of chunk ci; posts its progress every stage
+        //   wavefront 1   follows it stage by stage with the vector recursion (w, h_u, p, R~^-1 h_u, e)
+        //   wavefronts 2+ fetch the inputs of chunk ci+1, write the finished factor of chunk ci-1 back
+        // Two chunks in flight (inputs and factor double-buffered).
         int sb = 0;
-        double *const vr_base = ex.pool();
-        double *const vf_base = vr_base + 3 * (size_t)(CH + 1) * WR;
-        auto vr_of = [&](int ci) { return vr_base + (size_t)(ci % 3) * (CH + 1) * WR; };
-        auto vf_of = [&](int ci) { return vf_base + (size_t)(ci & 1) * CH * W4; };
+        const size_t buf = (size_t)(CH + 1) * WR + (size_t)CH * W4;
+        auto vr_of = [&](int ci) { return ex.pool() + (size_t)(ci & 1) * buf; };
+        auto vf_of = [&](int ci) { return vr_of(ci) + (size_t)(CH + 1) * WR; };
         auto k1_of = [&](int ci) { return Nl - ci * CH; };
         typename Ex::template PerLane<double> pr;   // wavefront 1, lanes < 12: p_{k+1}[lane]
         typename Ex::template PerLane<double> tr, wr;
@@ -687,9 +685,10 @@ struct Engine {
                 const double *ric = vr + (size_t)(k - klc) * WR;
                 const double *gt = ric + 48, *rbv = ric + 66;
                 double *fac = vf + (size_t)(k - k0c) * W4;
-                // P_{k+1}: next row of this chunk, or the seam copy left by the chunk above
-                const double *Pn = k < k1c ? fac + W4 + O_PM : sm.Pseam[(ci + 2) % 3];
+                // P_{k+1}: next row of this chunk, or the lowest row of the chunk above (other buffer, intact)
+                const double *Pn = (k < k1c ? fac + W4 : vf_of(ci + 1)) + O_PM;
                 const int vnxt = vcur ^ 1;
+                ex.await(&sm.prog, Nl - k);   // the matrices of stage k are in LDS
                 if (k == Nl) {
                     ex.sub([&](int lane) {
                         if (lane < NX) {
@@ -708,10 +707,9 @@ struct Engine {
                     // t = p_{k+1} + P_{k+1} rb_k (lane i < 12 owns component i)
                     double t = 0.0, w = 0.0;
                     if (lane < NX) {
-                        const double *Mn = Pn + lane * 12;
-                        double w0 = 0.0, w1 = 0.0;
+                        double w0 = 0.0, w1 = 0.0;   // row `lane` of the packed symmetric P_{k+1}
 #pragma unroll
-                        for (int j = 0; j < NX; j += 2) { w0 += Mn[j] * rbv[j]; w1 += Mn[j + 1] * rbv[j + 1]; }
+                        for (int j = 0; j < NX; j += 2) { w0 += Pn[tri_sym(lane, j)] * rbv[j]; w1 += Pn[tri_sym(lane, j + 1)] * rbv[j + 1]; }
                         w = w0 + w1;
                         t = pr.at(lane) + w;
                     }
@@ -751,20 +749,17 @@ struct Engine {
                 vcur = vnxt;
             }
         };
+        ex.par([&](int lane) { if (lane == 0) ex.post(&sm.prog, -1); });
         load_rect<WR, O_GQ, W2>(vr_of(0), c.w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
         int ci = 0;
-        for (int k1 = Nl; k1 >= -CH; k1 -= CH, ci++) {
-            // window ci: matrix recursion of chunk ci (none in the last window, which only drains)
-            const bool has_mat = k1 >= 0;
+        for (int k1 = Nl; k1 >= 0; k1 -= CH, ci++) {
             const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
             double *vr = vr_of(ci), *vf = vf_of(ci);
             const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);   // chunk ci+1
-            const int pk1 = k1 + CH, pk0 = imax(pk1 - CH + 1, 0);                            // chunk ci-1
-            if (!has_mat && ci == 0) break;
+            const int pk1 = k1 + CH, pk0 = k1 + 1;                                          // chunk ci-1
             PROF_T0(ts);
             ex.overlap3([&]() {
             PROF_T0(tx1);
-            if (has_mat)
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
@@ -773,13 +768,13 @@ struct Engine {
                 if (k == Nl) {
                     // terminal stage: no cost, no bounds -> P_N = 0 ; R~, S~ of stage N-1
                     ex.seq([&](int lane) {
-                        for (int e = lane; e < 144; e += WAVE) fac[O_PM + e] = 0.0;
-                        if (k == k0) for (int e = lane; e < 144; e += WAVE) sm.Pseam[ci % 3][e] = 0.0;
+                        for (int e = lane; e < NPM; e += WAVE) fac[O_PM + e] = 0.0;
                         if (lane < 36) {
                             FactLane &f = fl.at(lane);
                             f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
                             next_stage(lane, f, ricd + 36, sb);
                         }
+                        if (lane == 0) ex.post(&sm.prog, 0);
                     });
                     continue;
                 }
@@ -860,43 +855,26 @@ struct Engine {
                                 pvq -= sva[m] * kb[m]; pvv -= sva[m] * kvb[m];
                             }
                             f.mqq = pqq; f.mqv = pqv; f.mvq = pvq; f.mvv = pvv;
-                            fac[O_PM + f.a * 12 + f.b] = pqq;
-                            fac[O_PM + f.a * 12 + 6 + f.b] = pqv;
-                            fac[O_PM + (6 + f.a) * 12 + f.b] = pvq;
-                            fac[O_PM + (6 + f.a) * 12 + 6 + f.b] = pvv;
-                            if (k == k0) {                                 // lowest stage of the chunk: seam copy
-                                double *Mo = sm.Pseam[ci % 3];
-                                Mo[f.a * 12 + f.b] = pqq; Mo[f.a * 12 + 6 + f.b] = pqv;
-                                Mo[(6 + f.a) * 12 + f.b] = pvq; Mo[(6 + f.a) * 12 + 6 + f.b] = pvv;
-                            }
+                            // packed upper triangle: (a,b) of the qq and vv blocks only for a <= b, the qv block in full
+                            if (f.a <= f.b) { fac[O_PM + f.oqq] = pqq; fac[O_PM + f.ovv] = pvv; }
+                            fac[O_PM + f.oqv] = pqv;
                             next_stage(lane, f, ricd + 36, sb ^ 1);
                         }
                     }
+                    if (lane == 0) ex.post(&sm.prog, Nl - k);   // K_k, R~^-1_k, P_k are in LDS
                 });
                 sb ^= 1;
             }
             PROF_ADD(PF_X1, tx1);
             }, [&]() {
-                // wavefront 1: vector recursion of the previous chunk, then its h_u | p | w columns go home
-                if (ci > 0) {
-                    vec_sweep(ci - 1);
-                    ex.sub([&](int lane) {
-                        copy_lanes<30, O_VH, W4, W4, false, WAVE>(vf_of(ci - 1) + O_VH, c.w.G4, pk0, pk1, lane);   // R~^-1 h_u | e | p
-                        copy_lanes<12, O_WV, W4, W4, false, WAVE>(vf_of(ci - 1) + O_WV, c.w.G4, pk0, pk1, lane);
-                    });
-                }
+                vec_sweep(ci);   // wavefront 1: vector recursion of this chunk, one stage behind the matrices
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                if (has_mat && nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), c.w.G2, nkl, nk1, lane);
-                if (ci > 0) {
-                    copy_lanes<72, O_K, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
-                    copy_lanes<72, O_PM, W4, W4, false, NL>(vf_of(ci - 1) + O_PM, c.w.G4, pk0, pk1, lane);
-                    copy_lanes<72, O_PM + 72, W4, W4, false, NL>(vf_of(ci - 1) + O_PM + 72, c.w.G4, pk0, pk1, lane);
-                    copy_lanes<36, O_RI, W4, W4, false, NL>(vf_of(ci - 1) + O_RI, c.w.G4, pk0, pk1, lane);
-                }
+                if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), c.w.G2, nkl, nk1, lane);
+                if (ci > 0) copy_lanes<W4, 0, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
             });
             PROF_ADD(PF_SEQ_FACT, ts);
-            if (!has_mat) break;
+            if (k0 == 0) store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
         }
         PROF_ADD(PF_FACT, t0);
     }
@@ -1283,7 +1261,7 @@ struct Engine {
                             if (k >= 1) {
                                 double s0 = fac[(AFFINE ? 0 : O_PV) + j], s1 = 0.0;
 #pragma unroll
-                                for (int i = 0; i < NX; i += 2) { s0 += fac[(AFFINE ? 0 : O_PM) + j * 12 + i] * dxk[i]; s1 += fac[(AFFINE ? 0 : O_PM) + j * 12 + i + 1] * dxk[i + 1]; }
+                                for (int i = 0; i < NX; i += 2) { s0 += fac[(AFFINE ? 0 : O_PM) + tri_sym(j, i)] * dxk[i]; s1 += fac[(AFFINE ? 0 : O_PM) + tri_sym(j, i + 1)] * dxk[i + 1]; }
                                 v = s0 + s1;
                             }
                             o[18 + j] = v;                  // DPI slot of stage k holds dpi_{k-1}

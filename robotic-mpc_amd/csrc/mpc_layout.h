@@ -60,14 +60,15 @@ constexpr int O_DLAM = 96, O_DT = 120;
 // ---- G4 FACT ----------------------------------------------------------------------
 // Ordered by consumer: the forward sweeps read a prefix ([K..E] predictor, [K..P] final sweep), the
 // corrector reads K and the tail [w, R~^-1].
-constexpr int W4 = 294;
+constexpr int W4 = 228;
 constexpr int O_K = 0;      // Kfb = R~^-1 S~ (6x12)
 constexpr int O_VH = 72;    // R~^-1 h_u (6)
 constexpr int O_E = 78;     // e = rb - B R~^-1 h_u (12): the part of dx_{k+1} that does not depend on dx_k
 constexpr int O_PV = 90;    // p_k (12)
-constexpr int O_PM = 102;   // P_k (12x12)
-constexpr int O_WV = 246;   // w_k = P_{k+1} rb_k (12): reused by the corrector's backward solve
-constexpr int O_RI = 258;   // R~^-1 (6x6)
+constexpr int O_PM = 102;   // P_k, symmetric 12x12 PACKED: upper triangle by rows (78), see tri()
+constexpr int NPM = 78;
+constexpr int O_WV = 180;   // w_k = P_{k+1} rb_k (12): reused by the corrector's backward solve
+constexpr int O_RI = 192;   // R~^-1 (6x6)
 constexpr int W4_AFF = O_PV;   // what the predictor sweep loads
 constexpr int W4_FWD = O_WV;   // what the final forward sweep loads
 // ---- G5 SQPX ----------------------------------------------------------------------
@@ -132,6 +133,10 @@ struct Ws {
     double *G1, *G2, *G3, *G4, *G5, *state;
 };
 
+// offset of entry (r, c), r <= c, of a symmetric 12x12 matrix stored as its upper triangle by rows
+MPC_HD int tri(int r, int c) { return r * 12 - (r * (r - 1)) / 2 + (c - r); }
+MPC_HD int tri_sym(int i, int j) { return i <= j ? tri(i, j) : tri(j, i); }
+
 MPC_HD size_t ws_doubles_per_instance(int N) { return (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES; }
 
 MPC_HD Ws ws_carve(double *base, int N)
@@ -154,7 +159,6 @@ MPC_HD Ws ws_carve(double *base, int N)
 struct Smem {
     InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
     alignas(16) Robot rb;
-    alignas(16) double Pseam[3][144];  // lowest-stage P of the last three chunks of the factorisation sweep
     int prog;              // progress of the state recursion (last finished stage), Ex::post / await
     int prog_pad;
     alignas(16) double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)

@@ -9,13 +9,13 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ch = robots.builtin_chain("ur10")
 IT = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 cf = [config.resolve_config(config.base_params(prediction_horizon=N, simulation_time=0.01, solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": IT}))]
-W = dict(G1=96, G2=112, G3=144, G4=294, G5=116)
+W = dict(G1=96, G2=112, G3=144, G4=228, G5=116)
 def run(w, lib=None):
     os.environ["MPCB_WAVES_PER_SIM"] = str(w)
     eng = engine.MpcBatchEngine(0, lib_path=lib) if lib else engine.MpcBatchEngine(0)
     pb = eng.setup(cf, ch); bufs = eng.alloc_results(pb)
     eng.rollout(bufs, 0, 1); eng.sync()
-    n = (N + 1) * 762 + 64
+    n = (N + 1) * 696 + 64
     out = np.zeros(n)
     eng.lib.mpcb_debug_workspace.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t]
     rc = eng.lib.mpcb_debug_workspace(eng._h, 0, out.ctypes.data_as(C.POINTER(C.c_double)), n)
