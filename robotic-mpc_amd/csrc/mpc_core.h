@@ -38,6 +38,11 @@ namespace mpcb {
 
 constexpr double BOUND_INF = 1e29;
 
+// LDS row stride of a G1 (ITER) record in the chunk-parallel passes: 96 doubles = 768 B would put
+// the same column of EVERY stage on the same LDS banks (256-B bank period) -- lanes that work on
+// different stages of one column then serialise; 98 shifts consecutive stages by 16 B.
+constexpr int L1 = 98;
+
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
 #define PROF_ADD(i, v) prof[i] += ex.clock() - v
@@ -249,16 +254,16 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(N);
         const int W5M = 60;  // NPI, NLAM, NT
-        const int CH = chunk_len(W1 + W5M + W2, 2 * (W1 + W5M));
+        const int CH = chunk_len(L1 + W5M + W2, 2 * (L1 + W5M));
         double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
-            double *v1 = ex.pool();                       // rows lo..hi, W1
-            double *v5 = v1 + (size_t)(CH + 2) * W1;   // rows lo..hi, 60
+            double *v1 = ex.pool();                       // rows lo..hi, L1
+            double *v5 = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, 60
             double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, W2
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, lo, hi, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
                 if (sqp_mult) copy_lanes<60, 0, W5, 60, true, NL>(v5, c.w.G5, lo, hi, lane);
             });
             if (do_update) {
@@ -269,7 +274,7 @@ struct Engine {
                     for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW;
                         if (lo + s < k0) continue;
-                        double *r1 = v1 + (size_t)s * W1;
+                        double *r1 = v1 + (size_t)s * L1;
                         if (ci < 12) r1[O_X + ci] += alpha * r1[O_QW + 6 + ci];
                         else if (lo + s < Nl) r1[O_U + ci - 12] += alpha * r1[O_QW + ci - 12];
                     }
@@ -277,7 +282,7 @@ struct Engine {
                         for (int e = lane; e < rows * 60; e += NT) {
                             const int s = e / 60, ci = e - s * 60;
                             if (lo + s < k0) continue;
-                            const double *r1 = v1 + (size_t)s * W1;
+                            const double *r1 = v1 + (size_t)s * L1;
                             double *r5 = v5 + (size_t)s * 60;
                             // NPI | NLAM | NT  <-  blend towards QPI | QLAM | QT (contiguous in G1 from O_QPI)
                             r5[ci] += alpha * (r1[O_QPI + ci] - r5[ci]);
@@ -290,7 +295,7 @@ struct Engine {
                 for (int k = k0 + lane; k <= k1; k += NT) {
                     double *rec = v2 + (size_t)(k - k0) * W2;
                     if (k < Nl) {
-                        const double *r1 = v1 + (size_t)(k - lo) * W1, *rn = r1 + W1;
+                        const double *r1 = v1 + (size_t)(k - lo) * L1, *rn = r1 + L1;
                         double xx[12], uu[6];
 #pragma unroll
                         for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
@@ -327,14 +332,14 @@ struct Engine {
                     const int rows = k1 - k0 + 1;
                     for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW, k = k0 + s;
-                        const double *pi_k = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NPI : v1 + (size_t)(k - lo) * W1 + O_QPI;
+                        const double *pi_k = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NPI : v1 + (size_t)(k - lo) * L1 + O_QPI;
                         const double *pi_m = sqp_mult ? v5 + (size_t)(imax(k - 1, lo) - lo) * 60 + O_NPI
-                                                      : v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
-                        const double *lam = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NLAM : v1 + (size_t)(k - lo) * W1 + O_QLAM;
-                        const double *tt = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NT : v1 + (size_t)(k - lo) * W1 + O_QT;
-                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * W1, v2 + (size_t)s * W2, false, pi_k, pi_m);
+                                                      : v1 + (size_t)(imax(k - 1, lo) - lo) * L1 + O_QPI;
+                        const double *lam = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NLAM : v1 + (size_t)(k - lo) * L1 + O_QLAM;
+                        const double *tt = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NT : v1 + (size_t)(k - lo) * L1 + O_QT;
+                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * L1, v2 + (size_t)s * W2, false, pi_k, pi_m);
                         if (ci < NB && has_comp(Nl, k, ci)) {
-                            const double cur = v1[(size_t)(k - lo) * W1 + (ci < 6 ? O_U + ci : O_X + ci - 6)];
+                            const double cur = v1[(size_t)(k - lo) * L1 + (ci < 6 ? O_U + ci : O_X + ci - 6)];
                             if (bnd_lo(P, ci) > -BOUND_INF) {
                                 v -= lam[ci];
                                 a_i = fmax(a_i, fabs((bnd_lo(P, ci) - cur) + tt[ci]));
@@ -361,7 +366,7 @@ struct Engine {
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (do_update) {
-                    copy_lanes<18, 0, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1, c.w.G1, k0, k1, lane);
+                    copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, c.w.G1, k0, k1, lane);
                     if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, lane);
                 }
                 copy_lanes<W2_LIN, 0, W2, W2, false, NL>(v2, c.w.G2, k0, k1, lane);
@@ -431,22 +436,23 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         constexpr int W3D = 78, W3R = 66, WG = 42;
-        const int per = W1 + W3D + W2_LIN + W3R + WG;
-        const int CH = chunk_len(per, 2 * (W1 + W3D));
+        const int per = L1 + W3D + W2_LIN + W3R + WG;
+        const int CH = chunk_len(per, 2 * (L1 + W3D));
         double ng = 0, nb = 0, nd = 0, nm = 0, smu = 0, nc = 0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
-            double *v1 = ex.pool();                        // rows lo..hi, W1
-            double *v3d = v1 + (size_t)(CH + 2) * W1;   // rows lo..hi, DW|DPI|DLAM|DT
+            double *v1 = ex.pool();                        // rows lo..hi, L1
+            double *v3d = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, DW|DPI|DLAM|DT
             double *v2 = v3d + (size_t)(CH + 2) * W3D;  // rows k0..k1, compact [R..GV] (60)
             double *v3r = v2 + (size_t)CH * W2_LIN;     // rows k0..k1, RG|RD|RM
             double *vg = v3r + (size_t)CH * W3R;        // rows k0..k1, Gamma(12) | gt(18) | rb(12)
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, lo, hi, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
                 if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, c.w.G3, lo, hi, lane);
                 copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, c.w.G2, k0, k1, lane);
             });
+            PROF_T0(tx);
             ex.par([&](int lane) {
                 const int rows = hi - lo + 1;
                 double ncl = 0.0;
@@ -454,11 +460,11 @@ struct Engine {
                     // (lower halo row: already updated and stored by the previous chunk)
                     for (int e = lane; e < rows * NW; e += NT) {
                         const int s = e / NW, ci = e - s * NW;
-                        if (lo + s >= k0) v1[(size_t)s * W1 + O_QW + ci] += a * v3d[(size_t)s * W3D + ci];
+                        if (lo + s >= k0) v1[(size_t)s * L1 + O_QW + ci] += a * v3d[(size_t)s * W3D + ci];
                     }
                     for (int e = lane; e < (rows - 1) * NX; e += NT) {  // pi_k += a * dpi stored at stage k+1
                         const int s = e / NX, i = e - s * NX;
-                        if (lo + s >= k0 && lo + s < Nl) v1[(size_t)s * W1 + O_QPI + i] += a * v3d[(size_t)(s + 1) * W3D + 18 + i];
+                        if (lo + s >= k0 && lo + s < Nl) v1[(size_t)s * L1 + O_QPI + i] += a * v3d[(size_t)(s + 1) * W3D + 18 + i];
                     }
                 }
                 for (int e = lane; e < rows * NB; e += NT) {
@@ -466,7 +472,7 @@ struct Engine {
                     if (k < k0 || k > k1) continue;  // multipliers are only needed on own rows
                     const bool hc = has_comp(Nl, k, j);
                     const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
-                    double *lam = v1 + (size_t)s * W1 + O_QLAM, *t = v1 + (size_t)s * W1 + O_QT;
+                    double *lam = v1 + (size_t)s * L1 + O_QLAM, *t = v1 + (size_t)s * L1 + O_QT;
                     const double *dl = v3d + (size_t)s * W3D + 30, *dt = v3d + (size_t)s * W3D + 54;
                     if (mode == 0) {
                         if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
@@ -481,11 +487,13 @@ struct Engine {
                 }
                 if (mode == 0) {
                     if (lo == 0 && lane < NX) v1[O_QW + 6 + lane] = sm.xhat[lane] - v1[O_X + lane];
-                    if (hi == Nl && lane < NU) v1[(size_t)(Nl - lo) * W1 + O_QW + lane] = 0.0;
+                    if (hi == Nl && lane < NU) v1[(size_t)(Nl - lo) * L1 + O_QW + lane] = 0.0;
                 }
                 ex.put_sum(sm.red[5], lane, ncl);
             });
             if (mode == 0) nc += ex.get_sum(sm.red[5]);
+            PROF_ADD(PF_X1, tx);
+            PROF_T0(ty);
             // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
             ex.par([&](int lane) {
                 const int rows = k1 - k0 + 1;
@@ -493,7 +501,7 @@ struct Engine {
                     const int s = e / NTASK, i = e - s * NTASK, k = k0 + s;
                     double *r2 = v2 + (size_t)s * W2_LIN;
                     if (k >= Nl) continue;
-                    const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW;
+                    const double *dw = v1 + (size_t)(k - lo) * L1 + O_QW;
                     double v = r2[O_R + i];
 #pragma unroll
                     for (int j = 0; j < 6; j++) v += r2[O_GQ + i * 6 + j] * dw[6 + j];
@@ -504,6 +512,8 @@ struct Engine {
                     r2[O_Y + i] = P.w_task[i] * v;
                 }
             });
+            PROF_ADD(PF_X2, ty);
+            PROF_T0(tz);
             // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg.  Four kinds of rows -- u, q, v
             // components of the stationarity residual and the dynamics residual -- each have their own
             // formulas: a wavefront works on ONE kind at a time, so no lane diverges from its neighbours.
@@ -518,9 +528,9 @@ struct Engine {
                     constexpr int CLS = decltype(cls)::value;
                     for (int e = l6 + WAVE * part; e < rows * 6; e += WAVE * PARTS) {
                         const int s = e / 6, j = e - s * 6, ci = CLS * 6 + j, k = k0 + s;
-                        const double *r1 = v1 + (size_t)(k - lo) * W1;
+                        const double *r1 = v1 + (size_t)(k - lo) * L1;
                         const double *r2 = v2 + (size_t)s * W2_LIN;
-                        const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * W1 + O_QPI;
+                        const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * L1 + O_QPI;
                         double *o3 = v3r + (size_t)s * W3R, *og = vg + (size_t)s * 42;
                         double rg = stat_cls<CLS>(k, j, r1, r2, true, pk, pm);
                         double gt = rg;
@@ -567,7 +577,7 @@ struct Engine {
                             const int s = e / NX, i = e - s * NX, k = k0 + s;
                             double v = 0.0;
                             if (k < Nl) {
-                                const double *dw = v1 + (size_t)(k - lo) * W1 + O_QW, *dn = dw + W1;
+                                const double *dw = v1 + (size_t)(k - lo) * L1 + O_QW, *dn = dw + L1;
                                 if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
                                 else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
                                 v += v2[(size_t)s * W2_LIN + O_BD + i] - dn[6 + i];
@@ -585,9 +595,10 @@ struct Engine {
             nd = fmax(nd, ex.get_max(sm.red[2]));
             nm = fmax(nm, ex.get_max(sm.red[3]));
             smu += ex.get_sum(sm.red[4]);
+            PROF_ADD(PF_X3, tz);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<78, O_QW, W1, W1, false, NL>(v1 + (size_t)(k0 - lo) * W1 + O_QW, c.w.G1, k0, k1, lane);
+                copy_lanes<78, O_QW, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1 + O_QW, c.w.G1, k0, k1, lane);
                 copy_lanes<10, 0, W2, W2_LIN, false, NL>(v2, c.w.G2, k0, k1, lane);        // r (unchanged) and y
                 copy_lanes<WG, O_GAM, W2, WG, false, NL>(vg, c.w.G2, k0, k1, lane);        // Gamma | gt | rb
                 copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, c.w.G3, k0, k1, lane);         // RG | RD | RM
@@ -759,7 +770,6 @@ struct Engine {
             const int pk1 = k1 + CH, pk0 = k1 + 1;                                          // chunk ci-1
             PROF_T0(ts);
             ex.overlap3([&]() {
-            PROF_T0(tx1);
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
@@ -865,7 +875,6 @@ struct Engine {
                 });
                 sb ^= 1;
             }
-            PROF_ADD(PF_X1, tx1);
             }, [&]() {
                 vec_sweep(ci);   // wavefront 1: vector recursion of this chunk, one stage behind the matrices
             }, [&](int lane, auto nl) {
@@ -983,7 +992,6 @@ struct Engine {
             });
             PROF_T0(ts);
             ex.overlap([&]() {
-            PROF_T0(tx2);
             for (int k = k1; k >= k0; k--) {
                 const double *gt = vgr + (size_t)(k - k0) * WGR;
                 const double *cv = vc + (size_t)(k - k0) * WC;
@@ -1026,7 +1034,6 @@ struct Engine {
                 });
                 cur = nxt;
             }
-            PROF_ADD(PF_X2, tx2);
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk1 >= 0) {
@@ -1143,7 +1150,6 @@ struct Engine {
             const int nk0 = k1 + 1, nk1 = imin(nk0 + CH - 1, Nl);
             PROF_T0(ts);
             ex.overlap3([&]() {
-            PROF_T0(tx3);
             for (int k = k0; k <= k1; k++) {
                 const int nxt = cur ^ 1;
                 const double *fac = v4 + (size_t)(k - k0) * LF;
@@ -1175,7 +1181,6 @@ struct Engine {
                 });
                 if (k < Nl) cur = nxt;
             }
-            PROF_ADD(PF_X3, tx3);
             }, [&]() {
                 // wavefront 1 follows the recursion block by block: du_k = -(R~^-1 h_u + K dx_k), then
                 // dlam, dt (HPIPM compute_lam_t), largest feasible step, centering sums -- one phase,
@@ -1336,16 +1341,16 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(N);
         constexpr int WMW = 36;
-        const int CH = chunk_len(W1 + WMW + 16, W1);
+        const int CH = chunk_len(L1 + WMW + 16, L1);
         double total = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), hi = imin(k1 + 1, Nl);
-            double *v1 = ex.pool();                        // rows k0..hi, W1
-            double *vm = v1 + (size_t)(CH + 1) * W1;    // rows k0..k1, MW
+            double *v1 = ex.pool();                        // rows k0..hi, L1
+            double *vm = v1 + (size_t)(CH + 1) * L1;    // rows k0..k1, MW
             double *vt = vm + (size_t)CH * WMW;         // rows k0..k1, scratch r(5)
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, W1, true, NL>(v1, c.w.G1, k0, hi, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, k0, hi, lane);
                 copy_lanes<WMW, O_MW, W5, WMW, true, NL>(vm, c.w.G5, k0, k1, lane);
             });
             if (update_weights) {
@@ -1353,7 +1358,7 @@ struct Engine {
                     const int rows = k1 - k0 + 1;
                     for (int e = lane; e < rows * WMW; e += NT) {
                         const int s = e / WMW, i = e - s * WMW;
-                        const double *r1 = v1 + (size_t)s * W1;
+                        const double *r1 = v1 + (size_t)s * L1;
                         const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
                         double *mw = vm + (size_t)s * WMW + i;
                         *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
@@ -1364,7 +1369,7 @@ struct Engine {
             ex.par([&](int lane) {
                 double acc = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
-                    const double *r1 = v1 + (size_t)(k - k0) * W1, *rn = r1 + W1;
+                    const double *r1 = v1 + (size_t)(k - k0) * L1, *rn = r1 + L1;
                     const double *mw = vm + (size_t)(k - k0) * WMW;
                     double xx[12], uu[6], rec[8];  // task_lin<false> only writes rec[O_R..O_R+4]
 #pragma unroll
