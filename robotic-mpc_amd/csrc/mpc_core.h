@@ -42,6 +42,9 @@ constexpr double BOUND_INF = 1e29;
 // the same column of EVERY stage on the same LDS banks (256-B bank period) -- lanes that work on
 // different stages of one column then serialise; 98 shifts consecutive stages by 16 B.
 constexpr int L1 = 98;
+// same reason for the G2 record the NLP pass builds with one lane per stage (every lane touches the same
+// column of a different stage): 112 doubles would alias every second stage, 114 every sixteenth
+constexpr int L2N = 114;
 
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
@@ -254,13 +257,13 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(N);
         const int W5M = 60;  // NPI, NLAM, NT
-        const int CH = chunk_len(L1 + W5M + W2, 2 * (L1 + W5M));
+        const int CH = chunk_len(L1 + W5M + L2N, 2 * (L1 + W5M));
         double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
             double *v1 = ex.pool();                       // rows lo..hi, L1
             double *v5 = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, 60
-            double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, W2
+            double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, L2N
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
@@ -293,7 +296,7 @@ struct Engine {
             ex.par([&](int lane) {
                 double csum = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
-                    double *rec = v2 + (size_t)(k - k0) * W2;
+                    double *rec = v2 + (size_t)(k - k0) * L2N;
                     if (k < Nl) {
                         const double *r1 = v1 + (size_t)(k - lo) * L1, *rn = r1 + L1;
                         double xx[12], uu[6];
@@ -337,7 +340,7 @@ struct Engine {
                                                       : v1 + (size_t)(imax(k - 1, lo) - lo) * L1 + O_QPI;
                         const double *lam = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NLAM : v1 + (size_t)(k - lo) * L1 + O_QLAM;
                         const double *tt = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NT : v1 + (size_t)(k - lo) * L1 + O_QT;
-                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * L1, v2 + (size_t)s * W2, false, pi_k, pi_m);
+                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * L1, v2 + (size_t)s * L2N, false, pi_k, pi_m);
                         if (ci < NB && has_comp(Nl, k, ci)) {
                             const double cur = v1[(size_t)(k - lo) * L1 + (ci < 6 ? O_U + ci : O_X + ci - 6)];
                             if (bnd_lo(P, ci) > -BOUND_INF) {
@@ -353,7 +356,7 @@ struct Engine {
                         }
                         if (ci >= 6 && k == 0) v = 0.0;
                         a_s = fmax(a_s, fabs(v));
-                        if (ci < NX && k < Nl) a_e = fmax(a_e, fabs(v2[(size_t)s * W2 + O_BD + ci]));
+                        if (ci < NX && k < Nl) a_e = fmax(a_e, fabs(v2[(size_t)s * L2N + O_BD + ci]));
                     }
                     if (k0 == 0 && lane < NX) a_i = fmax(a_i, fabs(sm.xhat[lane] - v1[O_X + lane]));  // lbx_0 = ubx_0 = x_hat
                     ex.put_max(sm.red[0], lane, a_s); ex.put_max(sm.red[1], lane, a_e); ex.put_max(sm.red[2], lane, a_i); ex.put_max(sm.red[3], lane, a_c);
@@ -369,7 +372,7 @@ struct Engine {
                     copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, c.w.G1, k0, k1, lane);
                     if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, lane);
                 }
-                copy_lanes<W2_LIN, 0, W2, W2, false, NL>(v2, c.w.G2, k0, k1, lane);
+                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, c.w.G2, k0, k1, lane);
             });
         }
         if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
@@ -901,11 +904,11 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
         // LDS record of a stage: inputs | scratch | outputs.  Two chunks in flight (see fact_pass).
-        constexpr int WLT = 48;                  // QLAM | QT
+        constexpr int WLT = 50;                  // QLAM | QT (48 used; LDS strides of 48 would alias every 2nd stage on the banks)
         constexpr int L3 = 90;                   // RG 0 | RD 18 | DLAM 42 | DT 66  (G3 without RM and the step)
         constexpr int C_DLAM = 42, C_DT = 66;
         constexpr int WGR = 30;                  // GT 0 (rebuilt in place) | RB 18
-        constexpr int WK = 72, WW = 48;          // Kfb ; w = P_{k+1} rb_k (12) | R~^-1 (36)  (adjacent in G4)
+        constexpr int WK = 72, WW = 50;          // Kfb ; w = P_{k+1} rb_k (12) | R~^-1 (36)  (adjacent in G4)
         constexpr int WC = 12;                   // c_k: the part of p_k that does not depend on p_{k+1}
         constexpr int WRM = 24, WHP = 30;        // outputs: RM ; R~^-1 h_u (6) | e (12) | p (12)  (adjacent in G4)
         constexpr int C_PV = 18;
@@ -935,12 +938,12 @@ struct Engine {
             const int f0 = imax(Nl - CH + 1, 0);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(vlt, c.w.G1, f0, Nl, lane);
+                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(vlt, c.w.G1, f0, Nl, lane);
                 copy_lanes<42, 0, W3, L3, true, NL>(v3, c.w.G3, f0, Nl, lane);
                 copy_lanes<48, O_DLAM, W3, L3, true, NL>(v3 + C_DLAM, c.w.G3, f0, Nl, lane);
                 copy_lanes<WGR, O_GT, W2, WGR, true, NL>(vgr, c.w.G2, f0, Nl, lane);
                 copy_lanes<WK, O_K, W4, WK, true, NL>(vk, c.w.G4, f0, Nl, lane);
-                copy_lanes<WW, O_WV, W4, WW, true, NL>(vw, c.w.G4, f0, Nl, lane);
+                copy_lanes<48, O_WV, W4, WW, true, NL>(vw, c.w.G4, f0, Nl, lane);
             });
         }
         for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
@@ -1037,12 +1040,12 @@ struct Engine {
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk1 >= 0) {
-                    copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
+                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
                     copy_lanes<42, 0, W3, L3, true, NL>(n3, c.w.G3, nk0, nk1, lane);
                     copy_lanes<48, O_DLAM, W3, L3, true, NL>(n3 + C_DLAM, c.w.G3, nk0, nk1, lane);
                     copy_lanes<WGR, O_GT, W2, WGR, true, NL>(ngr, c.w.G2, nk0, nk1, lane);
                     copy_lanes<WK, O_K, W4, WK, true, NL>(nk, c.w.G4, nk0, nk1, lane);
-                    copy_lanes<WW, O_WV, W4, WW, true, NL>(nw, c.w.G4, nk0, nk1, lane);
+                    copy_lanes<48, O_WV, W4, WW, true, NL>(nw, c.w.G4, nk0, nk1, lane);
                 }
                 if (k1 < Nl) {
                     copy_lanes<WRM, O_RM, W3, WRM, false, NL>(prm, c.w.G3, k1 + 1, k1 + CH, lane);
@@ -1097,7 +1100,7 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(N);
-        constexpr int WLT = 48, WR = 48, WO = 78;
+        constexpr int WLT = 50, WR = 50, WO = 78;   // LDS row strides; 48 columns each are used (48 would alias every 2nd stage on the LDS banks)
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
         // K, R~^-1 h_u, e (no p, no P) and leaves only dlam, dt behind for the corrector
         constexpr int LF = AFFINE ? W4_AFF : W4_FWD;
@@ -1134,8 +1137,8 @@ struct Engine {
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<LF, 0, W4, LF, true, NL>(q4, c.w.G4, 0, e1, lane);
-                copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(qlt, c.w.G1, 0, e1, lane);
-                copy_lanes<WR, O_RD, W3, WR, true, NL>(qr, c.w.G3, 0, e1, lane);
+                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(qlt, c.w.G1, 0, e1, lane);
+                copy_lanes<48, O_RD, W3, WR, true, NL>(qr, c.w.G3, 0, e1, lane);
             });
         }
         for (int ci = 0; ci < NCH; ci++) {
@@ -1243,8 +1246,8 @@ struct Engine {
                 constexpr int NL = decltype(nl)::value;
                 if (nk0 <= Nl) {
                     copy_lanes<LF, 0, W4, LF, true, NL>(n4, c.w.G4, nk0, nk1, lane);
-                    copy_lanes<WLT, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
-                    copy_lanes<WR, O_RD, W3, WR, true, NL>(nr, c.w.G3, nk0, nk1, lane);
+                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
+                    copy_lanes<48, O_RD, W3, WR, true, NL>(nr, c.w.G3, nk0, nk1, lane);
                 }
                 if (k0 > 0) {
                     if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, c.w.G3, k0 - CH, k0 - 1, lane);
