@@ -1343,18 +1343,18 @@ struct Engine {
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(N);
-        constexpr int WMW = 36;
-        const int CH = chunk_len(L1 + WMW + 16, L1);
+        constexpr int WMW = 36, LMW = 38;   // 36 merit weights per stage; LDS row stride 38 (lane <-> stage accesses: no bank aliasing)
+        const int CH = chunk_len(L1 + LMW + 16, L1);
         double total = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), hi = imin(k1 + 1, Nl);
             double *v1 = ex.pool();                        // rows k0..hi, L1
             double *vm = v1 + (size_t)(CH + 1) * L1;    // rows k0..k1, MW
-            double *vt = vm + (size_t)CH * WMW;         // rows k0..k1, scratch r(5)
+            double *vt = vm + (size_t)CH * LMW;         // rows k0..k1, scratch r(5)
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, k0, hi, lane);
-                copy_lanes<WMW, O_MW, W5, WMW, true, NL>(vm, c.w.G5, k0, k1, lane);
+                copy_lanes<WMW, O_MW, W5, LMW, true, NL>(vm, c.w.G5, k0, k1, lane);
             });
             if (update_weights) {
                 ex.par([&](int lane) {
@@ -1363,17 +1363,17 @@ struct Engine {
                         const int s = e / WMW, i = e - s * WMW;
                         const double *r1 = v1 + (size_t)s * L1;
                         const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
-                        double *mw = vm + (size_t)s * WMW + i;
+                        double *mw = vm + (size_t)s * LMW + i;
                         *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
                     }
                 });
-                store_rect<WMW, O_MW, W5>(vm, c.w.G5, k0, k1);
+                copy_rect<WMW, O_MW, W5, LMW, false>(vm, c.w.G5, k0, k1);
             }
             ex.par([&](int lane) {
                 double acc = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
                     const double *r1 = v1 + (size_t)(k - k0) * L1, *rn = r1 + L1;
-                    const double *mw = vm + (size_t)(k - k0) * WMW;
+                    const double *mw = vm + (size_t)(k - k0) * LMW;
                     double xx[12], uu[6], rec[8];  // task_lin<false> only writes rec[O_R..O_R+4]
 #pragma unroll
                     for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i] + alpha * r1[O_QW + 6 + i];
