@@ -33,6 +33,7 @@
 
 // 16-way manual unrolling with individually named registers (see Engine::copy_lanes)
 #define MPC_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define MPC_REP4(X) X(0) X(1) X(2) X(3)
 
 namespace mpcb {
 
@@ -192,9 +193,11 @@ struct Engine {
             }
             return;
         }
-        const int col = imin(lane & (PITCH - 1), W2h - 1);
+        // lanes beyond the row's last 16-byte item sit out (a clamped duplicate would be a same-address
+        // LDS write conflict); rows beyond the last one are clamped, in groups of 4 or 16 instructions
+        const int col = lane & (PITCH - 1);
         const int r0 = lane >> SH;
-        for (int rb0 = 0; rb0 < rows; rb0 += RPI * 16) {
+        if (col >= W2h) return;
 #define MPC_AD(u)                                               \
     const int row##u = imin(rb0 + u * RPI + r0, rows - 1);      \
     MPC_GLOBAL D2 *gp##u = gb + (size_t)row##u * (LDG / 2) + col; \
@@ -203,13 +206,20 @@ struct Engine {
 #define MPC_ST(u)                  \
     if (LOAD) *lp##u = v##u;       \
     else *gp##u = v##u;
+        int rb0 = 0;
+        for (; rb0 + RPI * 4 < rows; rb0 += RPI * 16) {     // more than 4 instruction groups left
             MPC_REP16(MPC_AD)
             MPC_REP16(MPC_LD)
             MPC_REP16(MPC_ST)
+        }
+        if (rb0 < rows) {                                    // at most 4 groups left
+            MPC_REP4(MPC_AD)
+            MPC_REP4(MPC_LD)
+            MPC_REP4(MPC_ST)
+        }
 #undef MPC_AD
 #undef MPC_LD
 #undef MPC_ST
-        }
     }
     template <int W, int C0, int LDG, int LDL, bool LOAD>
     MPC_HD void copy_rect(double *l, double *g, int k_lo, int k_hi)
