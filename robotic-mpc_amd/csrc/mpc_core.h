@@ -43,9 +43,9 @@ constexpr double BOUND_INF = 1e29;
 // the same column of EVERY stage on the same LDS banks (256-B bank period) -- lanes that work on
 // different stages of one column then serialise; 98 shifts consecutive stages by 16 B.
 constexpr int L1 = 98;
-// same reason for the G2 record the NLP pass builds with one lane per stage (every lane touches the same
-// column of a different stage): 112 doubles would alias every second stage, 114 every sixteenth
-constexpr int L2N = 114;
+// same reason for the part [R..GV] (60 doubles) of the G2 record that the NLP pass builds with one
+// lane per stage (every lane touches the same column of a different stage): stride 62
+constexpr int L2N = 62;
 
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
@@ -267,13 +267,14 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(N);
         const int W5M = 60;  // NPI, NLAM, NT
-        const int CH = chunk_len(L1 + W5M + L2N, 2 * (L1 + W5M));
+        // SQP_RTI carries no NLP multipliers of its own: without them the whole N = 100 horizon is one chunk
+        const int CH = sqp_mult ? chunk_len(L1 + W5M + L2N, 2 * (L1 + W5M)) : chunk_len(L1 + L2N, 2 * L1);
         double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
             double *v1 = ex.pool();                       // rows lo..hi, L1
-            double *v5 = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, 60
-            double *v2 = v5 + (size_t)(CH + 2) * W5M;  // rows k0..k1, L2N
+            double *v5 = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, 60 (SQP only)
+            double *v2 = v5 + (sqp_mult ? (size_t)(CH + 2) * W5M : 0);  // rows k0..k1, L2N
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
