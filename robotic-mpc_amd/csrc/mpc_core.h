@@ -669,10 +669,12 @@ struct Engine {
         const double dw0 = P.dt * P.w_task[0], dw1 = P.dt * P.w_task[1], dw2 = P.dt * P.w_task[2], dw3 = P.dt * P.w_task[3],
                      dw4 = P.dt * P.w_task[4];
         // R~, S~ of stage `kd` from the lane's block of P_{kd+1}; also the A'MA block for stage kd
-        auto next_stage = [&](int lane, FactLane &f, const double *gam_kd, int sb) {
+        // (gam_u = Gamma_u[a] of stage kd, loaded by the caller together with its other LDS reads: a load
+        // inside the a == b branch would put a whole LDS round trip on the critical path)
+        auto next_stage = [&](int lane, FactLane &f, double gam_u, int sb) {
             const double fq = f.b1a * f.mqq + f.b2a * f.mvq, fv = f.b1a * f.mqv + f.b2a * f.mvv;
             double r = fq * f.b1b + fv * f.b2b + f.hu_c;
-            if (f.a == f.b) r += gam_kd[f.a];
+            r += f.a == f.b ? gam_u : 0.0;
             sm.Rt[f.a * 6 + f.b] = r;
             double *St = sm.St2[sb];
             St[f.a * 12 + f.b] = fq;
@@ -796,7 +798,7 @@ struct Engine {
                         if (lane < 36) {
                             FactLane &f = fl.at(lane);
                             f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
-                            next_stage(lane, f, ricd + 36, sb);
+                            next_stage(lane, f, ricd[36 + f.a], sb);
                         }
                         if (lane == 0) ex.post(&sm.prog, 0);
                     });
@@ -868,11 +870,12 @@ struct Engine {
                             const double ga0 = gq[f.a], ga1 = gq[6 + f.a], ga2 = gq[12 + f.a], ga3 = gq[18 + f.a], ga4 = gq[24 + f.a];
                             const double gb0 = gq[f.b], gb1 = gq[6 + f.b], gb2 = gq[12 + f.b], gb3 = gq[18 + f.b], gb4 = gq[24 + f.b];
                             const double gva = gv[f.a], gvb = gv[f.b];
+                            const double gam_q = gam[6 + f.a], gam_u = ricd[36 + f.a];   // unconditional (see next_stage)
                             double pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4);
                             double pqv = f.qqv + dw4 * ga4 * gvb;
                             double pvq = f.qvq + dw4 * gva * gb4;
                             double pvv = f.qvv + dw4 * gva * gvb + f.huv_c;
-                            if (f.a == f.b) pqq += gam[6 + f.a];
+                            pqq += f.a == f.b ? gam_q : 0.0;
 #pragma unroll
                             for (int m = 0; m < 6; m++) {
                                 pqq -= sa[m] * kb[m]; pqv -= sa[m] * kvb[m];
@@ -882,7 +885,7 @@ struct Engine {
                             // packed upper triangle: (a,b) of the qq and vv blocks only for a <= b, the qv block in full
                             if (f.a <= f.b) { fac[O_PM + f.oqq] = pqq; fac[O_PM + f.ovv] = pvv; }
                             fac[O_PM + f.oqv] = pqv;
-                            next_stage(lane, f, ricd + 36, sb ^ 1);
+                            next_stage(lane, f, gam_u, sb ^ 1);
                         }
                     }
                     if (lane == 0) ex.post(&sm.prog, Nl - k);   // K_k, R~^-1_k, P_k are in LDS
