@@ -495,8 +495,11 @@ struct Engine {
                         else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
                         ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
                     } else {
-                        if (blo) { lam[j] = fmax(lam[j] + a * dl[j], 1e-16); t[j] = fmax(t[j] + a * dt[j], 1e-16); }
-                        if (bhi) { lam[12 + j] = fmax(lam[12 + j] + a * dl[12 + j], 1e-16); t[12 + j] = fmax(t[12 + j] + a * dt[12 + j], 1e-16); }
+                        // all loads first (see corrector_bwd_pass)
+                        const double l0 = lam[j], t0_ = t[j], l1 = lam[12 + j], t1_ = t[12 + j];
+                        const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
+                        if (blo) { lam[j] = fmax(l0 + a * d0, 1e-16); t[j] = fmax(t0_ + a * e0, 1e-16); }
+                        if (bhi) { lam[12 + j] = fmax(l1 + a * d1, 1e-16); t[12 + j] = fmax(t1_ + a * e1, 1e-16); }
                     }
                 }
                 if (mode == 0) {
@@ -551,11 +554,14 @@ struct Engine {
                         if (CLS < 2) {
                             const bool hc = has_comp(Nl, k, ci);
                             const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
-                            const double v = hc ? r1[CLS == 0 ? O_U + j : O_X + j] : 0.0, dv = r1[O_QW + ci];
+                            const double v_ = r1[CLS == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
                             double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                            // all loads first, decisions on registers only (see corrector_bwd_pass)
+                            const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
+                            const double b_lo = bnd_lo(P, ci), b_hi = bnd_hi(P, ci);
                             if (blo) {
-                                const double l = r1[O_QLAM + ci], t = r1[O_QT + ci], it = fast_rcp(t);
-                                rdl = dv - (bnd_lo(P, ci) - v) - t;
+                                const double l = l_lo, t = t_lo, it = fast_rcp(t);
+                                rdl = dv - (b_lo - v) - t;
                                 rml = l * t;
                                 rg -= l; gt -= l;
                                 gam += l * it;
@@ -564,8 +570,8 @@ struct Engine {
                                 a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
                             }
                             if (bhi) {
-                                const double l = r1[O_QLAM + 12 + ci], t = r1[O_QT + 12 + ci], it = fast_rcp(t);
-                                rdu = (bnd_hi(P, ci) - v) - dv - t;
+                                const double l = l_hi, t = t_hi, it = fast_rcp(t);
+                                rdu = (b_hi - v) - dv - t;
                                 rmu = l * t;
                                 rg += l; gt += l;
                                 gam += l * it;
@@ -975,20 +981,19 @@ struct Engine {
                     const double *lt = vlt + (size_t)s * WLT;
                     const double *r3 = v3 + (size_t)s * L3;
                     double *rmo = orm + (size_t)s * WRM;
-                    double gt = r3[j], rml = 0.0, rmu = 0.0;
-                    if (has_comp(Nl, k, j)) {
-                        if (bnd_lo(P, j) > -BOUND_INF) {
-                            const double l = lt[j], t = lt[24 + j];
-                            rml = l * t + r3[C_DLAM + j] * r3[C_DT + j] - sigma_mu;
-                            gt += (rml + l * r3[18 + j]) * fast_rcp(t);
-                        }
-                        if (bnd_hi(P, j) < BOUND_INF) {
-                            const double l = lt[12 + j], t = lt[36 + j];
-                            rmu = l * t + r3[C_DLAM + 12 + j] * r3[C_DT + 12 + j] - sigma_mu;
-                            gt -= (rmu + l * r3[18 + 12 + j]) * fast_rcp(t);
-                        }
-                        vgr[(size_t)s * WGR + j] = gt;
-                    }
+                    // all loads first, decisions on registers only: an LDS load inside a branch costs a round trip
+                    // each (one wave per SIMD: nothing hides it).  Unbounded components hold lam = 0, t = 1.
+                    const bool hc = has_comp(Nl, k, j);
+                    const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                    const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
+                    const double dll = r3[C_DLAM + j], dtl = r3[C_DT + j], dlu = r3[C_DLAM + 12 + j], dtu = r3[C_DT + 12 + j];
+                    const double rdl = r3[18 + j], rdu = r3[18 + 12 + j];
+                    double gt = r3[j];
+                    const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
+                    const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
+                    gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
+                    gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                    if (hc) vgr[(size_t)s * WGR + j] = gt;
                     rmo[j] = rml; rmo[12 + j] = rmu;
                 }
             });
@@ -1226,23 +1231,25 @@ struct Engine {
                             } else {
                                 dv = dxk[j - 6];
                             }
+                            // all loads first, decisions on registers only (see corrector_bwd_pass)
                             const bool hc = has_comp(Nl, k, j);
+                            const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                            const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
+                            const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
                             double dtl = 0, dll = 0, dtu = 0, dlu = 0;
-                            if (hc && bnd_lo(P, j) > -BOUND_INF) {
-                                const double l = lt[j], t = lt[24 + j];
-                                dtl = dv + r[j];
-                                dll = -(r[24 + j] + l * dtl) * fast_rcp(t);
-                                if (dll < 0 && l + al * dll < 0) al = -l * fast_rcp(dll);
-                                if (dtl < 0 && t + al * dtl < 0) al = -t * fast_rcp(dtl);
-                                a0 += l * t; a1 += l * dtl + t * dll; a2 += dll * dtl;
+                            if (blo) {
+                                dtl = dv + rdl;
+                                dll = -(rml + ll * dtl) * fast_rcp(tl);
+                                if (dll < 0 && ll + al * dll < 0) al = -ll * fast_rcp(dll);
+                                if (dtl < 0 && tl + al * dtl < 0) al = -tl * fast_rcp(dtl);
+                                a0 += ll * tl; a1 += ll * dtl + tl * dll; a2 += dll * dtl;
                             }
-                            if (hc && bnd_hi(P, j) < BOUND_INF) {
-                                const double l = lt[12 + j], t = lt[36 + j];
-                                dtu = -dv + r[12 + j];
-                                dlu = -(r[36 + j] + l * dtu) * fast_rcp(t);
-                                if (dlu < 0 && l + al * dlu < 0) al = -l * fast_rcp(dlu);
-                                if (dtu < 0 && t + al * dtu < 0) al = -t * fast_rcp(dtu);
-                                a0 += l * t; a1 += l * dtu + t * dlu; a2 += dlu * dtu;
+                            if (bhi) {
+                                dtu = -dv + rdu;
+                                dlu = -(rmu + lu * dtu) * fast_rcp(tu);
+                                if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
+                                if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
+                                a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
                             }
                             o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
                             o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
