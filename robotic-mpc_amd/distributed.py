@@ -103,12 +103,25 @@ def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Calla
     simulation in queue order (rank 0; None on other ranks)."""
     ws, me = (world_size(), rank()) if use_dist else (1, 0)
     records: List[Optional[Dict[str, np.ndarray]]] = [None] * len(resolved)
-    for key, idxs in group_buckets(resolved).items():
+    buckets = list(group_buckets(resolved).items())
+    # a runner with submit()/collect() launches every bucket before the first result is awaited
+    # (buckets smaller than the GPU then overlap); a plain callable runs them one after the other
+    tickets = {}
+    if hasattr(runner, "submit"):
+        for key, idxs in buckets:
+            lo, hi = chunk_bounds(len(idxs), ws)[me]
+            mine = [resolved[i] for i in idxs[lo:hi]]
+            if mine:
+                tickets[key] = runner.submit(mine, chain_for(resolved[idxs[0]]))
+    for key, idxs in buckets:
         bounds = chunk_bounds(len(idxs), ws)
         lo, hi = bounds[me]
         mine = [resolved[i] for i in idxs[lo:hi]]
         chain = chain_for(resolved[idxs[0]])
-        local = runner(mine, chain) if mine else None
+        if key in tickets:
+            local = runner.collect(tickets.pop(key))
+        else:
+            local = runner(mine, chain) if mine else None
         if ws > 1:
             if local is None:  # this rank got no simulation of the bucket: contribute empty arrays
                 local = _empty_like_bucket(resolved[idxs[0]])

@@ -211,6 +211,42 @@ class Simulator:
 Runner = Callable[[Sequence[Dict], robots.KinematicChain], Dict[str, np.ndarray]]
 
 
+class _EngineRunner:
+    """Default runner: the HIP engine.  Callable (one bucket, synchronous) and, for queues with several
+    buckets, submit()/collect(): every bucket gets its own engine handle and HIP stream, so the
+    launches of small buckets (fewer simulations than CUs) overlap on the GPU."""
+
+    def __init__(self, device: int):
+        self.device = device
+        self._idle: list = []
+
+    def _engine(self):
+        from .engine import MpcBatchEngine
+
+        return self._idle.pop() if self._idle else MpcBatchEngine(self.device)
+
+    def __call__(self, cfgs, chain):
+        return self.collect(self.submit(cfgs, chain))
+
+    def submit(self, cfgs, chain):
+        import torch
+
+        eng = self._engine()
+        stream = torch.cuda.Stream(device=self.device)
+        pb = eng.setup(cfgs, chain)
+        with torch.cuda.stream(stream):
+            bufs = eng.alloc_results(pb)
+            eng.rollout(bufs, 0, pb.Nsim, stream=stream.cuda_stream)
+        return eng, stream, bufs
+
+    def collect(self, ticket):
+        eng, stream, bufs = ticket
+        stream.synchronize()
+        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        self._idle.append(eng)
+        return out
+
+
 class SimulationManager:
     """Parameter sweeps and grid searches, run as batched GPU launches."""
 
@@ -296,8 +332,7 @@ class SimulationManager:
             from .distributed import local_device
 
             dev = local_device()
-        eng = MpcBatchEngine(dev)
-        return lambda cfgs, chain: eng.run(cfgs, chain)
+        return _EngineRunner(dev)
 
     def run_all(self, return_results=True, distributed: Optional[bool] = None, checkpoint: Optional[str] = None):
         """Run every queued simulation (simulator.py:641-676).

@@ -228,3 +228,33 @@ def test_results_archive_round_trip_and_resume(orc, tmp_path):
     assert set(("names", "configs", "keys", "nsim", "z", "u", "status", "residuals")) <= set(arch)
     r0 = results_io.load_results(ck)[0]
     assert r0["summary"]["num_failures"] >= 0 and r0["simulator"].simulation_model.z.shape[0] == 12
+
+
+def test_runner_with_submit_collect_launches_all_buckets_first(orc):
+    """distributed.run_partitioned: a runner that offers submit()/collect() gets every bucket submitted before the
+    first collect (small buckets overlap on the GPU); results still come back in queue order."""
+    from robotic_mpc_amd import SimulationManager
+
+    log = []
+
+    class AsyncRunner:
+        def __call__(self, cfgs, chain):
+            raise AssertionError("the synchronous path must not be used when submit() exists")
+
+        def submit(self, cfgs, chain):
+            log.append(("submit", cfgs[0]["N"], len(cfgs)))
+            return cfgs, chain
+
+        def collect(self, ticket):
+            log.append(("collect", ticket[0][0]["N"]))
+            return hp.oracle_runner(*ticket)
+
+    m = SimulationManager(_base(), runner=AsyncRunner())
+    m.grid_search({"prediction_horizon": [4, 6], "w_qddot": [0.02, 0.05]})
+    res = m.run_all()
+    assert [e[0] for e in log] == ["submit", "submit", "collect", "collect"]
+    assert [r["simulator"].prediction_horizon for r in res] == [4, 4, 6, 6]
+    ref = SimulationManager(_base(), runner=hp.oracle_runner)
+    ref.grid_search({"prediction_horizon": [4, 6], "w_qddot": [0.02, 0.05]})
+    for a, b in zip(res, ref.run_all()):
+        np.testing.assert_array_equal(a["simulator"].simulation_model.z, b["simulator"].simulation_model.z)
