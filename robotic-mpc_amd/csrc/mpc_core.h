@@ -139,6 +139,9 @@ struct Engine {
 
     MPC_HD Engine(Ex &e, const Ctx &cc) : ex(e), c(cc), N(cc.N), lin_cost(0.0)
     {
+        ex.par([&](int lane) {
+            if (lane == 0) { Smem &sm = ex.smem(); sm.w = cc.w; sm.n_hor = cc.N; sm.pool_n = cc.pool_n; }
+        });
 #ifdef MPCB_PROFILE
         for (int i = 0; i < NPROF; i++) prof[i] = 0.0;
 #endif
@@ -249,8 +252,8 @@ struct Engine {
 
     MPC_HD int chunk_len(int per_stage, int halo_doubles) const
     {
-        const int ch = (c.pool_n - halo_doubles) / per_stage;
-        return ex.uni(imax(1, imin(ch, N + 1)));
+        const int ch = (ex.smem().pool_n - halo_doubles) / per_stage;
+        return ex.uni(imax(1, imin(ch, ex.smem().n_hor + 1)));
     }
 
     // =========================================================================== NLP pass
@@ -265,7 +268,7 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         const int W5M = 60;  // NPI, NLAM, NT
         // SQP_RTI carries no NLP multipliers of its own: without them the whole N = 100 horizon is one chunk
         const int CH = sqp_mult ? chunk_len(L1 + W5M + L2N, 2 * (L1 + W5M)) : chunk_len(L1 + L2N, 2 * L1);
@@ -277,8 +280,8 @@ struct Engine {
             double *v2 = v5 + (sqp_mult ? (size_t)(CH + 2) * W5M : 0);  // rows k0..k1, L2N
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
-                if (sqp_mult) copy_lanes<60, 0, W5, 60, true, NL>(v5, c.w.G5, lo, hi, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, lo, hi, lane);
+                if (sqp_mult) copy_lanes<60, 0, W5, 60, true, NL>(v5, ex.smem().w.G5, lo, hi, lane);
             });
             if (do_update) {
                 ex.par([&](int lane) {
@@ -380,10 +383,10 @@ struct Engine {
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (do_update) {
-                    copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, c.w.G1, k0, k1, lane);
-                    if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, c.w.G5, k0, k1, lane);
+                    copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, ex.smem().w.G1, k0, k1, lane);
+                    if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, ex.smem().w.G5, k0, k1, lane);
                 }
-                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, c.w.G2, k0, k1, lane);
+                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
             });
         }
         if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
@@ -448,7 +451,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int W3D = 78, W3R = 66, WG = 42;
         const int per = L1 + W3D + W2_LIN + W3R + WG;
         const int CH = chunk_len(per, 2 * (L1 + W3D));
@@ -462,9 +465,9 @@ struct Engine {
             double *vg = v3r + (size_t)CH * W3R;        // rows k0..k1, Gamma(12) | gt(18) | rb(12)
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, lo, hi, lane);
-                if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, c.w.G3, lo, hi, lane);
-                copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, c.w.G2, k0, k1, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, lo, hi, lane);
+                if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, ex.smem().w.G3, lo, hi, lane);
+                copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, ex.smem().w.G2, k0, k1, lane);
             });
             PROF_T0(tx);
             ex.par([&](int lane) {
@@ -618,10 +621,10 @@ struct Engine {
             PROF_ADD(PF_X3, tz);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<78, O_QW, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1 + O_QW, c.w.G1, k0, k1, lane);
-                copy_lanes<10, 0, W2, W2_LIN, false, NL>(v2, c.w.G2, k0, k1, lane);        // r (unchanged) and y
-                copy_lanes<WG, O_GAM, W2, WG, false, NL>(vg, c.w.G2, k0, k1, lane);        // Gamma | gt | rb
-                copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, c.w.G3, k0, k1, lane);         // RG | RD | RM
+                copy_lanes<78, O_QW, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1 + O_QW, ex.smem().w.G1, k0, k1, lane);
+                copy_lanes<10, 0, W2, W2_LIN, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);        // r (unchanged) and y
+                copy_lanes<WG, O_GAM, W2, WG, false, NL>(vg, ex.smem().w.G2, k0, k1, lane);        // Gamma | gt | rb
+                copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, ex.smem().w.G3, k0, k1, lane);         // RG | RD | RM
             });
         }
         nrm[0] = ng; nrm[1] = nb; nrm[2] = nd; nrm[3] = nm;
@@ -655,7 +658,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
         const int CH = chunk_len(2 * (WR + W4), 2 * WR);
         typename Ex::template PerLane<FactLane> fl;
@@ -783,7 +786,7 @@ struct Engine {
             }
         };
         ex.par([&](int lane) { if (lane == 0) ex.post(&sm.prog, -1); });
-        load_rect<WR, O_GQ, W2>(vr_of(0), c.w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
+        load_rect<WR, O_GQ, W2>(vr_of(0), ex.smem().w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
         int ci = 0;
         for (int k1 = Nl; k1 >= 0; k1 -= CH, ci++) {
             const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
@@ -902,11 +905,11 @@ struct Engine {
                 vec_sweep(ci);   // wavefront 1: vector recursion of this chunk, one stage behind the matrices
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), c.w.G2, nkl, nk1, lane);
-                if (ci > 0) copy_lanes<W4, 0, W4, W4, false, NL>(vf_of(ci - 1), c.w.G4, pk0, pk1, lane);
+                if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), ex.smem().w.G2, nkl, nk1, lane);
+                if (ci > 0) copy_lanes<W4, 0, W4, W4, false, NL>(vf_of(ci - 1), ex.smem().w.G4, pk0, pk1, lane);
             });
             PROF_ADD(PF_SEQ_FACT, ts);
-            if (k0 == 0) store_rect<W4, 0, W4>(vf, c.w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
+            if (k0 == 0) store_rect<W4, 0, W4>(vf, ex.smem().w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
         }
         PROF_ADD(PF_FACT, t0);
     }
@@ -922,7 +925,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         // LDS record of a stage: inputs | scratch | outputs.  Two chunks in flight (see fact_pass).
         constexpr int WLT = 50;                  // QLAM | QT (48 used; LDS strides of 48 would alias every 2nd stage on the banks)
         constexpr int L3 = 90;                   // RG 0 | RD 18 | DLAM 42 | DT 66  (G3 without RM and the step)
@@ -958,12 +961,12 @@ struct Engine {
             const int f0 = imax(Nl - CH + 1, 0);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(vlt, c.w.G1, f0, Nl, lane);
-                copy_lanes<42, 0, W3, L3, true, NL>(v3, c.w.G3, f0, Nl, lane);
-                copy_lanes<48, O_DLAM, W3, L3, true, NL>(v3 + C_DLAM, c.w.G3, f0, Nl, lane);
-                copy_lanes<WGR, O_GT, W2, WGR, true, NL>(vgr, c.w.G2, f0, Nl, lane);
-                copy_lanes<WK, O_K, W4, WK, true, NL>(vk, c.w.G4, f0, Nl, lane);
-                copy_lanes<48, O_WV, W4, WW, true, NL>(vw, c.w.G4, f0, Nl, lane);
+                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(vlt, ex.smem().w.G1, f0, Nl, lane);
+                copy_lanes<42, 0, W3, L3, true, NL>(v3, ex.smem().w.G3, f0, Nl, lane);
+                copy_lanes<48, O_DLAM, W3, L3, true, NL>(v3 + C_DLAM, ex.smem().w.G3, f0, Nl, lane);
+                copy_lanes<WGR, O_GT, W2, WGR, true, NL>(vgr, ex.smem().w.G2, f0, Nl, lane);
+                copy_lanes<WK, O_K, W4, WK, true, NL>(vk, ex.smem().w.G4, f0, Nl, lane);
+                copy_lanes<48, O_WV, W4, WW, true, NL>(vw, ex.smem().w.G4, f0, Nl, lane);
             });
         }
         for (int k1 = Nl; k1 >= 0; k1 -= CH, bsel ^= 1) {
@@ -1059,16 +1062,16 @@ struct Engine {
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk1 >= 0) {
-                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
-                    copy_lanes<42, 0, W3, L3, true, NL>(n3, c.w.G3, nk0, nk1, lane);
-                    copy_lanes<48, O_DLAM, W3, L3, true, NL>(n3 + C_DLAM, c.w.G3, nk0, nk1, lane);
-                    copy_lanes<WGR, O_GT, W2, WGR, true, NL>(ngr, c.w.G2, nk0, nk1, lane);
-                    copy_lanes<WK, O_K, W4, WK, true, NL>(nk, c.w.G4, nk0, nk1, lane);
-                    copy_lanes<48, O_WV, W4, WW, true, NL>(nw, c.w.G4, nk0, nk1, lane);
+                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, ex.smem().w.G1, nk0, nk1, lane);
+                    copy_lanes<42, 0, W3, L3, true, NL>(n3, ex.smem().w.G3, nk0, nk1, lane);
+                    copy_lanes<48, O_DLAM, W3, L3, true, NL>(n3 + C_DLAM, ex.smem().w.G3, nk0, nk1, lane);
+                    copy_lanes<WGR, O_GT, W2, WGR, true, NL>(ngr, ex.smem().w.G2, nk0, nk1, lane);
+                    copy_lanes<WK, O_K, W4, WK, true, NL>(nk, ex.smem().w.G4, nk0, nk1, lane);
+                    copy_lanes<48, O_WV, W4, WW, true, NL>(nw, ex.smem().w.G4, nk0, nk1, lane);
                 }
                 if (k1 < Nl) {
-                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(prm, c.w.G3, k1 + 1, k1 + CH, lane);
-                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(php, c.w.G4, k1 + 1, k1 + CH, lane);
+                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(prm, ex.smem().w.G3, k1 + 1, k1 + CH, lane);
+                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(php, ex.smem().w.G4, k1 + 1, k1 + CH, lane);
                 }
             });
             PROF_ADD(PF_SEQ_BWD, ts);
@@ -1099,8 +1102,8 @@ struct Engine {
             if (k0 == 0) {
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
-                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(orm, c.w.G3, k0, k1, lane);
-                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(ohp, c.w.G4, k0, k1, lane);
+                    copy_lanes<WRM, O_RM, W3, WRM, false, NL>(orm, ex.smem().w.G3, k0, k1, lane);
+                    copy_lanes<WHP, O_VH, W4, WHP, false, NL>(ohp, ex.smem().w.G4, k0, k1, lane);
                 });
             }
         }
@@ -1118,7 +1121,7 @@ struct Engine {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WLT = 50, WR = 50, WO = 78;   // LDS row strides; 48 columns each are used (48 would alias every 2nd stage on the LDS banks)
         // the affine (predictor) sweep only feeds the step length and the centering sums: it needs
         // K, R~^-1 h_u, e (no p, no P) and leaves only dlam, dt behind for the corrector
@@ -1155,9 +1158,9 @@ struct Engine {
             const int e1 = imin(CH - 1, Nl);
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<LF, 0, W4, LF, true, NL>(q4, c.w.G4, 0, e1, lane);
-                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(qlt, c.w.G1, 0, e1, lane);
-                copy_lanes<48, O_RD, W3, WR, true, NL>(qr, c.w.G3, 0, e1, lane);
+                copy_lanes<LF, 0, W4, LF, true, NL>(q4, ex.smem().w.G4, 0, e1, lane);
+                copy_lanes<48, O_QLAM, W1, WLT, true, NL>(qlt, ex.smem().w.G1, 0, e1, lane);
+                copy_lanes<48, O_RD, W3, WR, true, NL>(qr, ex.smem().w.G3, 0, e1, lane);
             });
         }
         for (int ci = 0; ci < NCH; ci++) {
@@ -1266,13 +1269,13 @@ struct Engine {
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk0 <= Nl) {
-                    copy_lanes<LF, 0, W4, LF, true, NL>(n4, c.w.G4, nk0, nk1, lane);
-                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, c.w.G1, nk0, nk1, lane);
-                    copy_lanes<48, O_RD, W3, WR, true, NL>(nr, c.w.G3, nk0, nk1, lane);
+                    copy_lanes<LF, 0, W4, LF, true, NL>(n4, ex.smem().w.G4, nk0, nk1, lane);
+                    copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, ex.smem().w.G1, nk0, nk1, lane);
+                    copy_lanes<48, O_RD, W3, WR, true, NL>(nr, ex.smem().w.G3, nk0, nk1, lane);
                 }
                 if (k0 > 0) {
-                    if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, c.w.G3, k0 - CH, k0 - 1, lane);
-                    else copy_lanes<WO, O_DW, W3, WO, false, NL>(po, c.w.G3, k0 - CH, k0 - 1, lane);
+                    if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, ex.smem().w.G3, k0 - CH, k0 - 1, lane);
+                    else copy_lanes<WO, O_DW, W3, WO, false, NL>(po, ex.smem().w.G3, k0 - CH, k0 - 1, lane);
                 }
                 if (!AFFINE) {
                     // copies issued: the copy wavefronts now follow the recursion too and form
@@ -1300,8 +1303,8 @@ struct Engine {
             });
             PROF_ADD(PF_SEQ_FWD, ts);
             if (k1 == Nl) {   // last chunk: nothing left to hide the store behind
-                if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), c.w.G3, k0, k1);
-                else store_rect<WO, O_DW, W3>(vo, c.w.G3, k0, k1);
+                if (AFFINE) copy_rect<48, O_DLAM, W3, WO, false>(const_cast<double *>(vo + 30), ex.smem().w.G3, k0, k1);
+                else store_rect<WO, O_DW, W3>(vo, ex.smem().w.G3, k0, k1);
             }
         }
         S[0] = ex.get1(sm.red[1]); S[1] = ex.get1(sm.red[2]); S[2] = ex.get1(sm.red[3]);
@@ -1363,7 +1366,7 @@ struct Engine {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const Robot &rb = sm.rb;
-        const int Nl = ex.uni(N);
+        const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WMW = 36, LMW = 38;   // 36 merit weights per stage; LDS row stride 38 (lane <-> stage accesses: no bank aliasing)
         const int CH = chunk_len(L1 + LMW + 16, L1);
         double total = 0.0;
@@ -1374,8 +1377,8 @@ struct Engine {
             double *vt = vm + (size_t)CH * LMW;         // rows k0..k1, scratch r(5)
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, L1, true, NL>(v1, c.w.G1, k0, hi, lane);
-                copy_lanes<WMW, O_MW, W5, LMW, true, NL>(vm, c.w.G5, k0, k1, lane);
+                copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, k0, hi, lane);
+                copy_lanes<WMW, O_MW, W5, LMW, true, NL>(vm, ex.smem().w.G5, k0, k1, lane);
             });
             if (update_weights) {
                 ex.par([&](int lane) {
@@ -1388,7 +1391,7 @@ struct Engine {
                         *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
                     }
                 });
-                copy_rect<WMW, O_MW, W5, LMW, false>(vm, c.w.G5, k0, k1);
+                copy_rect<WMW, O_MW, W5, LMW, false>(vm, ex.smem().w.G5, k0, k1);
             }
             ex.par([&](int lane) {
                 double acc = 0.0;
@@ -1445,7 +1448,7 @@ struct Engine {
         ex.par([&](int lane) {
             if (lane < NX) {
                 const InstParams &P = sm.P;
-                const double *r1 = c.w.G1, *r2 = c.w.G2;  // stage 0 records in HBM (y holds W(r + G delta))
+                const double *r1 = ex.smem().w.G1, *r2 = ex.smem().w.G2;  // stage 0 records in HBM (y holds W(r + G delta))
                 double v;
                 if (lane < 6) {
                     double s = 0.0;

@@ -159,6 +159,8 @@ MPC_HD Ws ws_carve(double *base, int N)
 struct Smem {
     InstParams P;       // this instance's parameters (lane-indexed reads stay on chip)
     alignas(16) Robot rb;
+    Ws w;                  // this instance's workspace pointers: kept here because the engine object lives in
+    int n_hor, pool_n;     // scratch memory inside a non-inlined pass (a flat load + full wait per use); LDS is ~10x closer
     int prog;              // progress of the state recursion (last finished stage), Ex::post / await
     int prog_pad;
     alignas(16) double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)
