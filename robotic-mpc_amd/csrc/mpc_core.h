@@ -410,6 +410,7 @@ struct Engine {
                            const double *pm) const
     {
         const InstParams &P = ex.smem().P;
+        const int N = ex.smem().n_hor;   // (shadows the member: that one lives in scratch memory inside a pass)
         double val = 0.0;
         if (CLS == 0) {
             if (k >= N) return 0.0;

@@ -8,6 +8,7 @@ from robotic_mpc_amd import robots, config, engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 T = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+SOLVER = sys.argv[4] if len(sys.argv) > 4 else "SQP_RTI"
 lib = os.environ.get("MPCB_LIB") or os.path.join(ROOT, "robotic-mpc_amd", "libmpcbatch_prof.so")
 eng = engine.MpcBatchEngine(0, lib_path=lib)
 print("kernel info", eng.kernel_info())
@@ -17,7 +18,8 @@ cf = []
 for i in range(B):
     c = config.resolve_config(config.base_params(prediction_horizon=N, simulation_time=T,
                                                  q_0=config.BASE_PARAMS["q_0"] + rng.uniform(-0.1, 0.1, 6),
-                                                 surface_coeffs=dict(a=0, b=0, c=0, d=0, e=0, f=0)))
+                                                 surface_coeffs=dict(a=0, b=0, c=0, d=0, e=0, f=0),
+                                                 solver_options={"nlp_solver_type": SOLVER}))
     cf.append(c)
 pb, bufs = eng.run_device(cf, ch)
 ms = sum(eng.last_kernel_ms)
