@@ -447,7 +447,10 @@ struct Engine {
     // lam, t >= 0.1, embed x0.  MODE 1: apply the Newton step with length `a` (HPIPM
     // update_var).  Then QP residuals, Gamma and the condensed gradient gt of the Newton system
     // (HPIPM compute_Gamma_gamma).  out: nrm = [g, b, d, m], smu = sum(lam*t), nc = #bound sides.
-    MPC_PASS void residual_pass(int mode, double a, double *nrm, double *smu_out, double *nc_out)
+    // Results (inf-norms of the four residuals, sum of complementarity products, number of
+    // constraints in mode 0) are left in sm.ret[0..5]: handing them back through pointers into the
+    // caller's frame costs scratch-memory round trips.
+    MPC_PASS void residual_pass(int mode, double a)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
@@ -628,9 +631,12 @@ struct Engine {
                 copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, ex.smem().w.G3, k0, k1, lane);         // RG | RD | RM
             });
         }
-        nrm[0] = ng; nrm[1] = nb; nrm[2] = nd; nrm[3] = nm;
-        *smu_out = smu;
-        if (nc_out) *nc_out = nc;
+        ex.par([&](int lane) {
+            if ((lane & (WAVE - 1)) == 0) {
+                sm.ret[0] = ng; sm.ret[1] = nb; sm.ret[2] = nd; sm.ret[3] = nm; sm.ret[4] = smu;
+                if (mode == 0) sm.ret[5] = nc;
+            }
+        });
         PROF_ADD(PF_RES, t0);
     }
 
@@ -1117,7 +1123,8 @@ struct Engine {
     // dx_{k+1} = A dx_k - B (Kfb dx_k + Rinv h_u) + rb_k is sequential (one phase per stage);
     // Rinv h_u and e = rb - B Rinv h_u come with the factor (written by whoever produced h_u).
     template <bool AFFINE>
-    MPC_PASS double forward_step_pass(double *S)
+    // (the centering sums S0, S1, S2 stay in sm.red[1..3][0]: read them with ex.get1)
+    MPC_PASS double forward_step_pass()
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
@@ -1308,7 +1315,6 @@ struct Engine {
                 else store_rect<WO, O_DW, W3>(vo, ex.smem().w.G3, k0, k1);
             }
         }
-        S[0] = ex.get1(sm.red[1]); S[1] = ex.get1(sm.red[2]); S[2] = ex.get1(sm.red[3]);
         const double alpha = ex.get1(sm.red[0]);
         PROF_ADD(PF_FWD, t0);
         return alpha;
@@ -1320,35 +1326,38 @@ struct Engine {
     MPC_HD int ipm_solve(int *iters_out)
     {
         const double tol = ex.smem().P.qp_tol;
-        double nrm[4], smu = 0.0, nc = 0.0, S[3];
-        residual_pass(0, 0.0, nrm, &smu, &nc);
-        double mu = nc > 0 ? smu / nc : 0.0;
+        Smem &sm = ex.smem();
+        residual_pass(0, 0.0);
+        const double nc = ex.uni(sm.ret[5]);
+        double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         int it = 0, status = 1;
         double alpha = 1.0;
         for (;; it++) {
             // every lane holds the same scalars; the decision is made uniform explicitly (scalar branch)
+            const double n0 = sm.ret[0], n1 = sm.ret[1], n2 = sm.ret[2], n3 = sm.ret[3];
             int stop = -1;
-            if (nrm[0] != nrm[0] || nrm[1] != nrm[1] || nrm[2] != nrm[2] || nrm[3] != nrm[3]) stop = 3;
-            else if (!(nrm[0] > tol || nrm[1] > tol || nrm[2] > tol || nrm[3] > tol)) stop = 0;
+            if (n0 != n0 || n1 != n1 || n2 != n2 || n3 != n3) stop = 3;
+            else if (!(n0 > tol || n1 > tol || n2 > tol || n3 > tol)) stop = 0;
             else if (it >= c.pb->qp_iter_max) stop = 1;
             else if (!(alpha > 1e-12)) stop = 2;
             stop = ex.uni(stop);
             if (stop >= 0) { status = stop; break; }
             fact_pass();
             const bool has_bounds = ex.uni(nc > 0);
-            const double a_aff = has_bounds ? forward_step_pass<true>(S) : forward_step_pass<false>(S);
+            const double a_aff = has_bounds ? forward_step_pass<true>() : forward_step_pass<false>();
             if (has_bounds) {
-                const double mu_aff = (S[0] + a_aff * (S[1] + a_aff * S[2])) / nc;
+                const double S0 = ex.get1(sm.red[1]), S1 = ex.get1(sm.red[2]), S2 = ex.get1(sm.red[3]);
+                const double mu_aff = (S0 + a_aff * (S1 + a_aff * S2)) / nc;
                 const double tmp = mu_aff / mu;
                 const double sigma = tmp * tmp * tmp;
                 corrector_bwd_pass(sigma * mu);
-                alpha = forward_step_pass<false>(S);
+                alpha = forward_step_pass<false>();
             } else {
                 alpha = a_aff;
             }
             const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
-            residual_pass(1, a, nrm, &smu, nullptr);
-            mu = nc > 0 ? smu / nc : 0.0;
+            residual_pass(1, a);
+            mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         }
 #ifdef MPCB_PROFILE
         prof[PF_COUNT_IPM] += it;
