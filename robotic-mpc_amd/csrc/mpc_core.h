@@ -1378,13 +1378,14 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WMW = 36, LMW = 38;   // 36 merit weights per stage; LDS row stride 38 (lane <-> stage accesses: no bank aliasing)
-        const int CH = chunk_len(L1 + LMW + 16, L1);
+        constexpr int LVT = 22;   // per-stage scratch in LDS: trial state (12) | task residual record (8); a local array would live in scratch memory
+        const int CH = chunk_len(L1 + LMW + LVT, L1);
         double total = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), hi = imin(k1 + 1, Nl);
             double *v1 = ex.pool();                        // rows k0..hi, L1
             double *vm = v1 + (size_t)(CH + 1) * L1;    // rows k0..k1, MW
-            double *vt = vm + (size_t)CH * LMW;         // rows k0..k1, scratch r(5)
+            double *vt = vm + (size_t)CH * LMW;         // rows k0..k1, trial point and its task residual
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, k0, hi, lane);
@@ -1408,7 +1409,8 @@ struct Engine {
                 for (int k = k0 + lane; k <= k1; k += NT) {
                     const double *r1 = v1 + (size_t)(k - k0) * L1, *rn = r1 + L1;
                     const double *mw = vm + (size_t)(k - k0) * LMW;
-                    double xx[12], uu[6], rec[8];  // task_lin<false> only writes rec[O_R..O_R+4]
+                    double *xx = vt + (size_t)(k - k0) * LVT, *rec = xx + 12;   // task_lin<false> only writes rec[O_R..O_R+4]
+                    double uu[6];
 #pragma unroll
                     for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i] + alpha * r1[O_QW + 6 + i];
                     if (k < Nl) {
@@ -1426,23 +1428,19 @@ struct Engine {
                             const double xnv = rn[O_X + 6 + j] + alpha * rn[O_QW + 12 + j];
                             acc += mw[j] * fabs((xx[j] + P.a12[j] * xx[6 + j] + P.b1[j] * uu[j]) - xnq);
                             acc += mw[6 + j] * fabs((P.a22[j] * xx[6 + j] + P.b2[j] * uu[j]) - xnv);
+                            // branch-free (every lane-dependent branch costs a saved exec mask: this phase ran out of SGPRs)
                             const double vl = P.umin[j] - uu[j], vu = uu[j] - P.umax[j];
-                            if (vl > 0) acc += mw[12 + j] * vl;
-                            if (vu > 0) acc += mw[24 + j] * vu;
-                            if (k >= 1) {
-                                const double ql = P.qmin[j] - xx[j], qu = xx[j] - P.qmax[j];
-                                if (ql > 0) acc += mw[18 + j] * ql;
-                                if (qu > 0) acc += mw[30 + j] * qu;
-                            }
+                            acc += mw[12 + j] * fmax(vl, 0.0) + mw[24 + j] * fmax(vu, 0.0);
+                            const double ql = P.qmin[j] - xx[j], qu = xx[j] - P.qmax[j], on = k >= 1 ? 1.0 : 0.0;
+                            acc += on * (mw[18 + j] * fmax(ql, 0.0) + mw[30 + j] * fmax(qu, 0.0));
                         }
                         acc += 0.5 * P.dt * s;
                     }
                     if (k == 0) {
 #pragma unroll
-                        for (int i = 0; i < 12; i++) acc += c.w.state[13 + i] * fabs(sm.xhat[i] - xx[i]);
+                        for (int i = 0; i < 12; i++) acc += sm.w.state[13 + i] * fabs(sm.xhat[i] - xx[i]);
                     }
                 }
-                (void)vt;
                 ex.put_sum(sm.red[0], lane, acc);
             });
             total += ex.get_sum(sm.red[0]);
@@ -1473,7 +1471,7 @@ struct Engine {
                         P.a22[jj] * r1[O_QPI + 6 + jj];
                 }
                 const double a = fabs(v);
-                double *mw = &c.w.state[13 + lane];
+                double *mw = &ex.smem().w.state[13 + lane];
                 *mw = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mw + a));
             }
         });
