@@ -88,6 +88,17 @@ MPC_HD double bnd_hi(const InstParams &P, int j) { return j < 6 ? P.umax[j] : P.
 MPC_HD int imin(int a, int b) { return a < b ? a : b; }
 MPC_HD int imax(int a, int b) { return a > b ? a : b; }
 
+// 24-bit multiply (full rate; a 32-bit integer multiply is a quarter-rate v_mul_lo / v_mad_u64_u32 on gfx950):
+// row * stride products of the chunk copies stay far below 2^24
+MPC_HD int mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
 // 1/d for the LDL' pivots and the slack divisions of the interior-point formulas: hardware reciprocal seed (measured 4.6e-8 relative on gfx950,
 // scripts/microbench/rcptest.hip) + one third-order correction x (1 + e + e^2), e = 1 - d x:
 // three dependent FMAs to full fp64 accuracy instead of the ~40-instruction IEEE division on the
@@ -182,11 +193,12 @@ struct Engine {
         if (FLAT) {
             const int tot = rows * W2h;
             for (int base = 0; base < tot; base += NL * 16) {
-#define MPC_AD(u) const int e##u = imin(base + u * NL + lane, tot - 1);
-#define MPC_LD(u) const D2 v##u = LOAD ? gb[e##u] : lb[e##u];
+#define MPC_AD(u) const int e##u = imin(base + u * NL + lane, tot - 1); \
+    MPC_GLOBAL D2 *gq##u = (MPC_GLOBAL D2 *)((MPC_GLOBAL char *)gb + (unsigned)(e##u * 16));
+#define MPC_LD(u) const D2 v##u = LOAD ? *gq##u : lb[e##u];
 #define MPC_ST(u)                  \
     if (LOAD) lb[e##u] = v##u;     \
-    else gb[e##u] = v##u;
+    else *gq##u = v##u;
                 MPC_REP16(MPC_AD)
                 MPC_REP16(MPC_LD)
                 MPC_REP16(MPC_ST)
@@ -203,8 +215,8 @@ struct Engine {
         if (col >= W2h) return;
 #define MPC_AD(u)                                               \
     const int row##u = imin(rb0 + u * RPI + r0, rows - 1);      \
-    MPC_GLOBAL D2 *gp##u = gb + (size_t)row##u * (LDG / 2) + col; \
-    MPC_LOCAL D2 *lp##u = lb + (size_t)row##u * (LDL / 2) + col;
+    MPC_GLOBAL D2 *gp##u = (MPC_GLOBAL D2 *)((MPC_GLOBAL char *)gb + (unsigned)(mul24(row##u, LDG * 8) + col * 16)); /* scalar base + 32-bit byte offset */ \
+    MPC_LOCAL D2 *lp##u = (MPC_LOCAL D2 *)((MPC_LOCAL char *)lb + (mul24(row##u, LDL * 8) + col * 16));
 #define MPC_LD(u) const D2 v##u = LOAD ? *gp##u : *lp##u;
 #define MPC_ST(u)                  \
     if (LOAD) *lp##u = v##u;       \
