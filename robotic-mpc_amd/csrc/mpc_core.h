@@ -1056,6 +1056,12 @@ struct Engine {
                 }
                 // p_k = c_k + Acl' p_{k+1}: p_{k+1} travels lane to lane in registers (no LDS round trip)
                 ex.seq([&](int lane) {
+                    // this stage's column of K and c entry first (their LDS latency runs under the gather)
+                    const int jc = lane < NX ? lane : 0;
+                    double kc[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) kc[i] = kf[i * 12 + jc];
+                    const double ck = cv[jc];
                     const double mine = pr.at(lane);
                     double pn[12];
 #pragma unroll
@@ -1067,11 +1073,11 @@ struct Engine {
                         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
                         for (int i = 0; i < 6; i += 2) {
-                            acc0 += kf[i * 12 + j] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
-                            acc1 += kf[(i + 1) * 12 + j] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
+                            acc0 += kc[i] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
+                            acc1 += kc[i + 1] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
                         }
                         const double at = j < 6 ? mine : c2.x * oq + c2.y * mine;
-                        const double pj = cv[j] + (at - (acc0 + acc1));
+                        const double pj = ck + (at - (acc0 + acc1));
                         pr.at(lane) = pj; ex.share(sm.pv[nxt], lane, pj);
                         hp[C_PV + j] = pj;
                     }
@@ -1201,24 +1207,30 @@ struct Engine {
                 double *o = vo + (size_t)(k - k0) * WO;
                 // dx_{k+1} = e_k + A dx_k - B K dx_k: dx_k travels lane to lane in registers
                 ex.seq([&](int lane) {
+                    // this stage's row of K and e entry first: their LDS latency runs under the 24 v_readlane
+                    // of the gather instead of after it (all lanes load, from clamped in-range addresses)
+                    const int lc = lane < NX ? lane : 0, i = lc < 6 ? lc : lc - 6;
+                    double kr[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) kr[j] = fac[O_K + i * 12 + j];
+                    const double ek = fac[O_E + lc];
                     const double own = dxr.at(lane);
                     double dxv[12];
 #pragma unroll
                     for (int j = 0; j < NX; j++) dxv[j] = ex.gather(sm.dx[cur], j, own);
                     const double ov = ex.shl6(sm.dx[cur], lane, own);   // lanes 0..5: dx_k[6 + lane]
                     if (lane < NX) {
-                        const int i = lane < 6 ? lane : lane - 6;
                         o[6 + lane] = own;   // dx_k
                         if (k < Nl) {
                             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                             for (int j = 0; j < NX; j += 2) {
-                                s0 += fac[O_K + i * 12 + j] * dxv[j];
-                                s1 += fac[O_K + i * 12 + j + 1] * dxv[j + 1];
+                                s0 += kr[j] * dxv[j];
+                                s1 += kr[j + 1] * dxv[j + 1];
                             }
                             const double kd = s0 + s1;
                             const D2 a = ab.at(lane), b = bb.at(lane);
-                            const double v = fac[O_E + lane] + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                            const double v = ek + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
                             dxr.at(lane) = v; ex.share(sm.dx[nxt], lane, v);
                         }
                     }
