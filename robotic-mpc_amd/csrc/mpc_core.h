@@ -1067,19 +1067,19 @@ struct Engine {
 #pragma unroll
                     for (int i = 0; i < NX; i++) pn[i] = ex.gather(sm.pv[cur], i, mine);
                     const double oq = ex.shr6(sm.pv[cur], lane, mine);   // lanes 6..11: p_{k+1}[lane - 6]
-                    if (lane < NX) {
-                        const int j = lane;
-                        const D2 c2 = ab.at(lane);
-                        double acc0 = 0.0, acc1 = 0.0;
+                    double acc0 = 0.0, acc1 = 0.0;   // (in every lane, see forward_step_pass)
 #pragma unroll
-                        for (int i = 0; i < 6; i += 2) {
-                            acc0 += kc[i] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
-                            acc1 += kc[i + 1] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
-                        }
-                        const double at = j < 6 ? mine : c2.x * oq + c2.y * mine;
-                        const double pj = ck + (at - (acc0 + acc1));
-                        pr.at(lane) = pj; ex.share(sm.pv[nxt], lane, pj);
-                        hp[C_PV + j] = pj;
+                    for (int i = 0; i < 6; i += 2) {
+                        acc0 += kc[i] * (b1r[i] * pn[i] + b2r[i] * pn[6 + i]);
+                        acc1 += kc[i + 1] * (b1r[i + 1] * pn[i + 1] + b2r[i + 1] * pn[7 + i]);
+                    }
+                    const D2 c2 = ab.at(lane);
+                    const double at = lane < 6 ? mine : c2.x * oq + c2.y * mine;
+                    const double pj = ck + (at - (acc0 + acc1));
+                    pr.at(lane) = pj;                       // unconditional (see forward_step_pass)
+                    if (lane < NX) {
+                        ex.share(sm.pv[nxt], lane, pj);
+                        hp[C_PV + lane] = pj;
                     }
                 });
                 cur = nxt;
@@ -1219,20 +1219,23 @@ struct Engine {
 #pragma unroll
                     for (int j = 0; j < NX; j++) dxv[j] = ex.gather(sm.dx[cur], j, own);
                     const double ov = ex.shl6(sm.dx[cur], lane, own);   // lanes 0..5: dx_k[6 + lane]
+                    // (the dot product runs in every lane: inside the lane < 12 branch the compiler sinks the loads
+                    // into the branch, behind the gather)
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; j += 2) {
+                        s0 += kr[j] * dxv[j];
+                        s1 += kr[j + 1] * dxv[j + 1];
+                    }
+                    const double kd = s0 + s1;
+                    // the register update is unconditional too (lanes >= 12 carry a harmless value): anything the
+                    // compiler can prove is only needed by lanes < 12 it sinks into that branch, loads included
+                    const D2 a = ab.at(lane), b = bb.at(lane);
+                    const double v = ek + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                    dxr.at(lane) = v;   // (also at k = N, where it is never used again)
                     if (lane < NX) {
                         o[6 + lane] = own;   // dx_k
-                        if (k < Nl) {
-                            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                            for (int j = 0; j < NX; j += 2) {
-                                s0 += kr[j] * dxv[j];
-                                s1 += kr[j + 1] * dxv[j + 1];
-                            }
-                            const double kd = s0 + s1;
-                            const D2 a = ab.at(lane), b = bb.at(lane);
-                            const double v = ek + (lane < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
-                            dxr.at(lane) = v; ex.share(sm.dx[nxt], lane, v);
-                        }
+                        if (k < Nl) ex.share(sm.dx[nxt], lane, v);
                     }
                     if (lane == 0) ex.post(&sm.prog, k);   // dx_k is in LDS (an unconditional post is cheaper than a modulo)
                 });
