@@ -14,7 +14,7 @@
  *     solver.get_residuals(), get_cost()         simulator.py:219,221
  * plus the plant step and logging of simulation_model.Robot.update
  * (simulation_model.py:85-91).  Where the reference builds and drives ONE solver per
- * simulation, this ABI takes a BATCH of simulations (one 64-double parameter record each)
+ * simulation, this ABI takes a BATCH of simulations (one 72-double parameter record each)
  * and runs all closed loops on the GPU, one wavefront per simulation.
  *
  * Conventions: plain C, no exceptions; every function returns 0 on success or a negative
@@ -32,8 +32,8 @@
 extern "C" {
 #endif
 
-#define MPCB_VERSION 100      /* 0.1.0 */
-#define MPCB_NPARAM 64        /* doubles per simulation, layout below */
+#define MPCB_VERSION 200      /* 0.2.0 */
+#define MPCB_NPARAM 72        /* doubles per simulation, layout below */
 #define MPCB_NROBOT 105       /* doubles of kinematic constants, layout below */
 
 #define MPCB_OK 0
@@ -67,7 +67,11 @@ typedef struct {
  *   [8..13] wcv   [14..19] q_0   [20..25] qdot_0   [26..31] q_min   [32..37] q_max
  *   [38..43] qdot_min (lbu)   [44..49] qdot_max (ubu)
  *   [50..55] surface_coeffs a,b,c,d,e,f (surface.py:14-17)
- *   [56..60] task weights (trajectory_optimizer.py:44-48, all 50.0)   [61..63] reserved
+ *   [56..60] task weights (trajectory_optimizer.py:44-48, all 50.0)
+ *   [61] nlp_solver_tol_eq [62] nlp_solver_tol_ineq [63] nlp_solver_tol_comp -- 0 means "same as [1]", which is
+ *        nlp_solver_tol_stat (any acados option reaches the solver through simulator.py:129-135)
+ *   [64] levenberg_marquardt (acados: dt*lm*I added to every stage Hessian, lm*I to the terminal one)
+ *   [65..71] reserved (0)
  * Bounds with |value| >= 1e29 are treated as absent.
  *
  * Kinematic constants, MPCB_NROBOT doubles (what loader.py:24-36 extracts from the URDF):
@@ -89,8 +93,12 @@ typedef struct {
     int *qp_iter;        /* [batch][Nsim]    interior-point iterations   */
     double *residuals;   /* [batch][Nsim][4] stat, eq, ineq, comp        */
     double *cost;        /* [batch][Nsim]                                */
-    double *solver_time; /* [batch][Nsim]    seconds on the device       */
+    double *solver_time; /* [batch][Nsim]    seconds on the device (one whole closed-loop step) */
+    double *errors;      /* [batch][7][T1]   e1..e5, p_task_z, p_ee_y of Simulator.errors (simulator.py:265-344),
+                                             computed with the log column on the device                  */
 } mpcb_result;
+
+#define MPCB_NSUMMARY 24      /* doubles per simulation written by mpcb_summary, layout below */
 
 int mpcb_version(void);
 /* Number of HIP devices visible; 0 when none (never an error by itself). */
@@ -128,6 +136,16 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
 /* Launch geometry chosen by mpcb_setup for the current batch: wavefronts cooperating on one
  * simulation (one workgroup per simulation), and the dynamic-LDS chunk pool per workgroup. */
 int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes);
+
+/* Replaces Simulator.metrics / solver_stats / timings / get_summary (simulator.py:347-448, 509-547) for the whole
+ * batch: one pass over the device logs of a finished rollout.  `out_dev` as for mpcb_rollout; `summary_dev` is a
+ * DEVICE array [batch][MPCB_NSUMMARY]:
+ *   [0..4] rmse_e1..e5  [5..9] itse_e1..e5  [10] weighted_rmse  [11] total_sqp_iterations  [12] avg_sqp_iterations
+ *   [13] num_failures  [14] max_kkt_residual  [15] total_solver_time  [16] avg_mpc_time  [17] avg_solver_time
+ *   [18] avg_integration_time  [19] total_computation_time  [20] total_qp_iterations  [21..23] reserved.
+ * The device times a whole closed-loop step; `plant_time_fraction` in [0,1] of it is reported as the plant update
+ * (integration_time, simulator.py:224-226) and the rest as the solve (mpc_time, simulator.py:209-214).  Asynchronous. */
+int mpcb_summary(mpcb_handle *h, const mpcb_result *out_dev, double plant_time_fraction, double *summary_dev, void *stream);
 
 /* Convenience for callers without device buffers of their own: setup + rollout(0,Nsim) +
  * copy-back into HOST arrays `out_host`. */

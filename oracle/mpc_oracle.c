@@ -864,6 +864,8 @@ static void linearize(orc_solver *s)
                     Hk[a * NW + c] = s->p.dt * h;
                 }
             }
+            /* acados ocp_nlp_approximate_qp_matrices: "Levenberg Marquardt term: Ts[i] * levenberg_marquardt * eye()" */
+            for (int a = 0; a < NW; a++) Hk[a * NW + a] += s->p.dt * s->p.lm;
             const double *xn = s->x + (size_t)(k + 1) * 12;
             double *bk = s->b + (size_t)k * 12;
             for (int i = 0; i < 12; i++) {
@@ -872,6 +874,10 @@ static void linearize(orc_solver *s)
                 for (int j = 0; j < 6; j++) v += s->B[i * 6 + j] * uk[j];
                 bk[i] = v;
             }
+        }
+        else {
+            /* terminal stage: "1.0 * levenberg_marquardt * eye()" on the nx x nx block (nu_N = 0) */
+            for (int a = 6; a < NW; a++) Hk[a * NW + a] += s->p.lm;
         }
         double *lbk = s->lb + (size_t)k * 12, *ubk = s->ub + (size_t)k * 12;
         for (int j = 0; j < 6; j++) {
@@ -1054,7 +1060,11 @@ int orc_solver_step(orc_solver *s, const double *xhat, double *u0, int *sqp_iter
         for (sqp_iter = 0; sqp_iter < s->p.max_iter; sqp_iter++) {
             linearize(s);
             nlp_residuals(s, xhat, res);
-            if (res[0] < s->p.tol && res[1] < s->p.tol && res[2] < s->p.tol && res[3] < s->p.tol) { status = 0; break; }
+            {   /* acados ocp_nlp_sqp: res_stat < tol_stat && res_eq < tol_eq && res_ineq < tol_ineq && res_comp < tol_comp */
+                const double te = s->p.tol_eq > 0 ? s->p.tol_eq : s->p.tol, ti = s->p.tol_ineq > 0 ? s->p.tol_ineq : s->p.tol,
+                             tc = s->p.tol_comp > 0 ? s->p.tol_comp : s->p.tol;
+                if (res[0] < s->p.tol && res[1] < te && res[2] < ti && res[3] < tc) { status = 0; break; }
+            }
             if (res[0] != res[0] || s->cost != s->cost) { status = 1; break; }
             int qs = solve_qp(s, xhat, &it);
             qp_iter += it;

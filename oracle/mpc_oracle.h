@@ -54,6 +54,11 @@ typedef struct {
     double coeffs[6]; /* a b c d e f, surface.py:14-17 */
     double w_task[5]; /* trajectory_optimizer.py:44-48 (all 50.0) */
     int integrator;   /* plant integrator, simulation_model.py:39-49: 0 RK4 (simulator.py:85), 1 Euler, 2 RK2, 3 RK3 */
+    /* acados nlp_solver_tol_eq / _ineq / _comp (`tol` above is nlp_solver_tol_stat); a value <= 0 means
+     * "same as tol" (the acados `tol` setter writes all four; simulator.py:129-135 forwards any of them) */
+    double tol_eq, tol_ineq, tol_comp;
+    /* acados levenberg_marquardt (default 0): dt*lm*I is added to every stage Hessian, lm*I to the terminal one */
+    double lm;
 } orc_params;
 
 /* Per-instance outputs, C-contiguous [row][time] like the reference's logs

@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("qmin", C.c_double * 6), ("qmax", C.c_double * 6), ("umin", C.c_double * 6), ("umax", C.c_double * 6),
         ("w_u", C.c_double), ("w_qddot", C.c_double), ("px_ref", C.c_double), ("vy_ref", C.c_double),
         ("coeffs", C.c_double * 6), ("w_task", C.c_double * 5), ("integrator", C.c_int),
+        ("tol_eq", C.c_double), ("tol_ineq", C.c_double), ("tol_comp", C.c_double), ("lm", C.c_double),
     ]
 
 
@@ -86,6 +87,8 @@ def make_params(cfg: Dict) -> Params:
     p.w_u = float(cfg["w_u"]); p.w_qddot = float(cfg["w_qddot"])
     p.px_ref = float(cfg["px_ref"]); p.vy_ref = float(cfg["vy_ref"])
     p.integrator = int(cfg.get("plant_integrator", 0))
+    p.tol_eq = float(cfg.get("tol_eq", 0.0)); p.tol_ineq = float(cfg.get("tol_ineq", 0.0)); p.tol_comp = float(cfg.get("tol_comp", 0.0))
+    p.lm = float(cfg.get("levenberg_marquardt", 0.0))
     return p
 
 

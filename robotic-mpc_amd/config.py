@@ -53,13 +53,20 @@ DEFAULT_SOLVER_OPTIONS = {
     "qp_solver_warm_start": 2,
     "nlp_solver_warm_start_first_qp": True,
     "print_level": 0,
+    # acados defaults of options the reference never sets but forwards when given (simulator.py:129-135)
+    "levenberg_marquardt": 0.0,
+    "nlp_solver_tol_stat": 1e-6, "nlp_solver_tol_eq": 1e-6, "nlp_solver_tol_ineq": 1e-6, "nlp_solver_tol_comp": 1e-6,
 }
-# Options the single native QP/NLP implementation accepts but that do not change results.
+_NLP_TOLS = ("nlp_solver_tol_stat", "nlp_solver_tol_eq", "nlp_solver_tol_ineq", "nlp_solver_tol_comp")
+_QP_TOLS = ("qp_solver_tol_stat", "qp_solver_tol_eq", "qp_solver_tol_ineq", "qp_solver_tol_comp")
+# Options that select HOW the QP is solved, not WHAT it is: the GN QP is strictly convex, so its solution
+# (to qp_tol) does not depend on condensing or on the Riccati variant.  The engine has one
+# QP method (Mehrotra IPM on the sparse OCP-QP, HPIPM semantics); these are accepted without effect.
 _ACCEPTED_NOOP = {
-    "qp_solver", "qp_solver_cond_N", "print_level", "qp_solver_warm_start", "nlp_solver_warm_start_first_qp",
-    "N_horizon", "tf", "qp_solver_cond_ric_alg", "qp_solver_ric_alg", "regularize_method", "ext_fun_compile_flags",
-    "nlp_solver_tol_stat", "nlp_solver_tol_eq", "nlp_solver_tol_ineq", "nlp_solver_tol_comp",
+    "qp_solver_cond_N", "print_level", "N_horizon", "tf", "qp_solver_cond_ric_alg", "qp_solver_ric_alg",
+    "ext_fun_compile_flags",
 }
+_QP_SOLVERS_EQUIVALENT = ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM")
 
 # The common synthetic base of SURVEY.md 8(d) (readme.md:27-43, surface_stats.ipynb cell 1).
 BASE_PARAMS: Dict[str, Any] = {
@@ -110,11 +117,36 @@ def resolve_solver_options(options: Optional[Mapping[str, Any]]) -> Dict[str, An
         return out
     if not isinstance(options, Mapping):
         raise TypeError("solver_options must be a dict (simulator.py:131 iterates .items())")
-    for key, value in options.items():
-        if key in out or key in _ACCEPTED_NOOP:
+    qp_tols = {}
+    for key, value in options.items():   # in dict order, like the setattr loop of the reference
+        if key == "tol":
+            # acados_template's `tol` setter writes all four NLP tolerances
+            out["tol"] = value
+            for k in _NLP_TOLS:
+                out[k] = value
+        elif key in _QP_TOLS:
+            qp_tols[key] = value
+        elif key in out or key in _ACCEPTED_NOOP:
             out[key] = value
         else:
             warnings.warn(f"Warning: Unknown solver option '{key}'")
+    # options that would change results and that the engine does not implement are errors, never ignored
+    for key, value in qp_tols.items():
+        if float(value) != float(out["qp_tol"]):
+            raise ValueError(f"{key}={value} differs from qp_tol={out['qp_tol']}: the engine's interior point takes one "
+                             f"tolerance for all four QP residuals (set qp_tol)")
+    if out["qp_solver"] not in _QP_SOLVERS_EQUIVALENT:
+        raise ValueError(f"qp_solver '{out['qp_solver']}' is not available: the engine solves the OCP-QP with an HPIPM-style "
+                         f"interior point ({', '.join(_QP_SOLVERS_EQUIVALENT)} give the same solution to qp_tol)")
+    if int(out["qp_solver_warm_start"]) != 2 or not out["nlp_solver_warm_start_first_qp"]:
+        raise ValueError("only qp_solver_warm_start=2 with nlp_solver_warm_start_first_qp=True is implemented "
+                         "(trajectory_optimizer.py:69-70)")
+    if "regularize_method" in options and options["regularize_method"] not in (None, "NO_REGULARIZE"):
+        raise ValueError("regularize_method other than NO_REGULARIZE is not implemented")
+    for k in _NLP_TOLS + ("qp_tol", "levenberg_marquardt"):
+        out[k] = float(out[k])
+        if not out[k] >= 0.0 or (k != "levenberg_marquardt" and out[k] == 0.0):
+            raise ValueError(f"solver option {k} must be positive")
     if out["nlp_solver_type"] not in ("SQP", "SQP_RTI"):
         raise ValueError(f"nlp_solver_type '{out['nlp_solver_type']}' not supported (SQP, SQP_RTI)")
     if out["hessian_approx"] != "GAUSS_NEWTON":
@@ -169,7 +201,9 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
         "N": N, "Nsim": Nsim, "dt": dt,
         "solver_type": SOLVER_RTI if so["nlp_solver_type"] == "SQP_RTI" else SOLVER_SQP,
         "max_iter": int(so["nlp_solver_max_iter"]), "qp_iter_max": int(so["qp_solver_iter_max"]),
-        "tol": float(so["tol"]), "qp_tol": float(so["qp_tol"]),
+        # `tol` of the parameter record is nlp_solver_tol_stat; the other three travel beside it
+        "tol": so["nlp_solver_tol_stat"], "tol_eq": so["nlp_solver_tol_eq"], "tol_ineq": so["nlp_solver_tol_ineq"],
+        "tol_comp": so["nlp_solver_tol_comp"], "qp_tol": so["qp_tol"], "levenberg_marquardt": so["levenberg_marquardt"],
         "fixed_step": so["globalization"] == "FIXED_STEP",
         "wcv": wcv, "q0": _vec6(cfg, "q_0"), "qdot0": _vec6(cfg, "qdot_0"),
         "qmin": _vec6(cfg, "q_min"), "qmax": _vec6(cfg, "q_max"),

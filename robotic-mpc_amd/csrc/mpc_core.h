@@ -431,6 +431,7 @@ struct Engine {
             const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
             val = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
             val += P.b1[j] * pk[j] + P.b2[j] * pk[6 + j];
+            if (with_delta) val += P.dt * P.lm * r1[O_QW + j];   // levenberg_marquardt: dt*lm*I on the stage Hessian
         } else if (CLS == 1) {
             if (k == 0) return 0.0;
             if (k < N) {
@@ -439,6 +440,7 @@ struct Engine {
                 for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
                 val = P.dt * s + pk[j];
             }
+            if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 6 + j];   // terminal stage: lm*I
             val -= pm[j];
         } else {
             if (k == 0) return 0.0;
@@ -449,6 +451,7 @@ struct Engine {
                 val = P.dt * (r2[O_GV + j] * r2[O_Y + 4] + c2 * (vj - uj));
                 val += P.a12[j] * pk[j] + P.a22[j] * pk[6 + j];
             }
+            if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 12 + j];
             val -= pm[6 + j];
         }
         return val;
@@ -664,8 +667,9 @@ struct Engine {
     //       R~, S~ of stage k-1; lanes 40..51: h_u, p_k
     struct FactLane {
         double b1a, b2a, b1b, b2b, a12a, a22a, a12b, a22b;
-        double hu_c;     // dt (2 w_u + w_qddot c_a^2) on the diagonal of R~, 0 off it
+        double hu_c;     // dt (2 w_u + w_qddot c_a^2 + lm) on the diagonal of R~, 0 off it
         double huv_c;    // dt w_qddot c_a^2 on the diagonals, 0 off them
+        double lm_c;     // dt lm on the diagonals of H_qq, H_vv (levenberg_marquardt), 0 off them
         double mqq, mqv, mvq, mvv;   // P_{k+1} block (a,b)
         double qqq, qqv, qvq, qvv;   // A' P_{k+1} A block (a,b)
         int a, b;
@@ -689,8 +693,9 @@ struct Engine {
             f.b1a = P.b1[a]; f.b2a = P.b2[a]; f.b1b = P.b1[b]; f.b2b = P.b2[b];
             f.a12a = P.a12[a]; f.a22a = P.a22[a]; f.a12b = P.a12[b]; f.a22b = P.a22[b];
             const double c2 = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
-            f.hu_c = a == b ? P.dt * 2.0 * P.w_u + c2 : 0.0;
+            f.hu_c = a == b ? P.dt * 2.0 * P.w_u + c2 + P.dt * P.lm : 0.0;
             f.huv_c = a == b ? c2 : 0.0;
+            f.lm_c = a == b ? P.dt * P.lm : 0.0;
             f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
             f.qqq = f.qqv = f.qvq = f.qvv = 0.0;
         });
@@ -820,12 +825,15 @@ struct Engine {
                 double *fac = vf + (size_t)(k - k0) * W4;
                 const double *gam = ric + 36;
                 if (k == Nl) {
-                    // terminal stage: no cost, no bounds -> P_N = 0 ; R~, S~ of stage N-1
+                    // terminal stage: no cost, no bounds -> P_N = lm I (0 without levenberg_marquardt) ; R~, S~ of stage N-1
                     ex.seq([&](int lane) {
+                        const double lmN = ex.smem().P.lm;
                         for (int e = lane; e < NPM; e += WAVE) fac[O_PM + e] = 0.0;
+                        if (lane < NX) fac[O_PM + tri(lane, lane)] = lmN;   // (same wavefront, program order: after the zero fill)
                         if (lane < 36) {
                             FactLane &f = fl.at(lane);
-                            f.mqq = f.mqv = f.mvq = f.mvv = 0.0;
+                            f.mqv = f.mvq = 0.0;
+                            f.mqq = f.mvv = f.a == f.b ? lmN : 0.0;
                             next_stage(lane, f, ricd[36 + f.a], sb);
                         }
                         if (lane == 0) ex.post(&sm.prog, 0);
@@ -899,10 +907,10 @@ struct Engine {
                             const double gb0 = gq[f.b], gb1 = gq[6 + f.b], gb2 = gq[12 + f.b], gb3 = gq[18 + f.b], gb4 = gq[24 + f.b];
                             const double gva = gv[f.a], gvb = gv[f.b];
                             const double gam_q = gam[6 + f.a], gam_u = ricd[36 + f.a];   // unconditional (see next_stage)
-                            double pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4);
+                            double pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4) + f.lm_c;
                             double pqv = f.qqv + dw4 * ga4 * gvb;
                             double pvq = f.qvq + dw4 * gva * gb4;
-                            double pvv = f.qvv + dw4 * gva * gvb + f.huv_c;
+                            double pvv = f.qvv + dw4 * gva * gvb + (f.huv_c + f.lm_c);
                             pqq += f.a == f.b ? gam_q : 0.0;
 #pragma unroll
                             for (int m = 0; m < 6; m++) {
@@ -1489,13 +1497,13 @@ struct Engine {
                     double s = 0.0;
 #pragma unroll
                     for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + lane] * r2[O_Y + i];
-                    v = P.dt * s + r1[O_QPI + lane];
+                    v = P.dt * s + r1[O_QPI + lane] + P.dt * P.lm * r1[O_QW + 6 + lane];
                 } else {
                     const int jj = lane - 6;
                     const double uj = r1[O_U + jj] + r1[O_QW + jj], vj = r1[O_X + 6 + jj] + r1[O_QW + 12 + jj];
                     const double c2 = P.w_qddot * P.cq[jj] * P.cq[jj];
                     v = P.dt * (r2[O_GV + jj] * r2[O_Y + 4] + c2 * (vj - uj)) + P.a12[jj] * r1[O_QPI + jj] +
-                        P.a22[jj] * r1[O_QPI + 6 + jj];
+                        P.a22[jj] * r1[O_QPI + 6 + jj] + P.dt * P.lm * r1[O_QW + 12 + jj];
                 }
                 const double a = fabs(v);
                 double *mw = &ex.smem().w.state[13 + lane];
@@ -1538,7 +1546,7 @@ struct Engine {
             cost = nlp_pass(1.0, ok, false, res4);
             lin_valid = true;
         } else {
-            const double tol = ex.smem().P.tol;
+            const double tol = ex.smem().P.tol, tol_eq = ex.smem().P.tol_eq, tol_in = ex.smem().P.tol_ineq, tol_co = ex.smem().P.tol_comp;
             status = 2;  // ACADOS_MAXITER unless decided otherwise
             double alpha = 0.0;
             bool pending = false;  // a step (alpha) waits to be applied by the next nlp_pass
@@ -1548,7 +1556,7 @@ struct Engine {
                     pending = false;
                     lin_valid = true;
                 }
-                if (ex.uni(res4[0] < tol && res4[1] < tol && res4[2] < tol && res4[3] < tol)) { status = 0; break; }
+                if (ex.uni(res4[0] < tol && res4[1] < tol_eq && res4[2] < tol_in && res4[3] < tol_co)) { status = 0; break; }
                 if (ex.uni(res4[0] != res4[0] || cost != cost)) { status = 1; break; }
                 const int qs = ipm_solve(&it);
                 qp_iter += it;
@@ -1576,6 +1584,7 @@ struct Engine {
         const int Nsim = c.pb->Nsim;
         const size_t sb = (size_t)inst * Nsim;
         bool lin_valid = false;
+        int log_lo = step0 == 0 ? 0 : step0 + 1;   // first log column this launch produces
         if (step0 == 0) {
             // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0 (SURVEY A.7 iv)
             const size_t tot = (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES;
@@ -1590,7 +1599,7 @@ struct Engine {
                 if (lane < NX) sm.xhat[lane] = lane < 6 ? P.q0[lane] : P.qdot0[lane - 6];
                 if (lane < NU) sm.u0[lane] = P.qdot0[lane];  // u[:,0] = qdot_0 (simulator.py:81)
             });
-            log_state(out, inst, 0);
+            log_lo = ex.uni(log_state(out, inst, 0, log_lo));
         } else {
             ex.par([&](int lane) {
                 if (lane < NX) sm.xhat[lane] = w.state[lane];
@@ -1650,9 +1659,10 @@ struct Engine {
             ex.par([&](int lane) {
                 if (lane < NX) sm.xhat[lane] = sm.logv[24 + lane];
             });
-            log_state(out, inst, i + 1);
+            log_lo = ex.uni(log_state(out, inst, i + 1, log_lo));
             PROF_ADD(PF_PLANT, tp);
         }
+        if (log_lo <= step1) log_flush(out, inst, log_lo, step1);   // the columns of a partly filled block
         ex.par([&](int lane) {
             if (lane < NX) w.state[lane] = sm.xhat[lane];
             if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; }
@@ -1667,30 +1677,54 @@ struct Engine {
         });
     }
 
-    // simulation_model.py:87-90: log state, input, FK pose, rpy, J*qdot at column `col`
-    MPC_PASS void log_state(const Outputs &out, int inst, int col)
+    // simulation_model.py:87-90: log state, input, FK pose, rpy, J*qdot at column `col`, plus the task errors of
+    // Simulator.errors (simulator.py:265-344) of that column.  Columns collect in LDS (sm.logbuf) and leave as
+    // contiguous runs of up to LOGB columns per row: `log_lo` = first column of the current block still in LDS.
+    MPC_PASS int log_state(const Outputs &out, int inst, int col, int log_lo)
     {
         Smem &sm = ex.smem();
         const Robot &rb = sm.rb;
-        const int T1 = c.pb->Nsim + 1;
         ex.par([&](int lane) {
             if (lane == 0) {
                 double z[12];
 #pragma unroll
                 for (int i = 0; i < 12; i++) z[i] = sm.xhat[i];
                 plant_log(rb, z, sm.logv);
+                task_errors(sm.P, rb, sm.logv, sm.logv + 15, sm.logv + 36);
             }
         });
         ex.par([&](int lane) {
-            if (lane < 12) {
-                out.z[((size_t)inst * 12 + lane) * T1 + col] = sm.xhat[lane];
-                out.ee_pose[((size_t)inst * 12 + lane) * T1 + col] = sm.logv[lane];
-            } else if (lane < 18) {
-                out.u[((size_t)inst * 6 + (lane - 12)) * T1 + col] = sm.u0[lane - 12];
-            } else if (lane < 21) {
-                out.ee_rpy[((size_t)inst * 3 + (lane - 18)) * T1 + col] = sm.logv[12 + (lane - 18)];
-            } else if (lane < 27) {
-                out.ee_vel[((size_t)inst * 6 + (lane - 21)) * T1 + col] = sm.logv[15 + (lane - 21)];
+            if (lane < LOG_ROWS) {
+                const double v = lane < 12 ? sm.xhat[lane]
+                               : lane < 18 ? sm.u0[lane - 12]
+                               : lane < 30 ? sm.logv[lane - 18]
+                               : lane < 33 ? sm.logv[12 + (lane - 30)]
+                               : lane < 39 ? sm.logv[15 + (lane - 33)]
+                                           : sm.logv[36 + (lane - 39)];
+                sm.logbuf[lane][col & (LOGB - 1)] = v;
+            }
+        });
+        col = ex.uni(col); log_lo = ex.uni(log_lo);   // wave-uniform: scalar branch
+        if ((col & (LOGB - 1)) == LOGB - 1) { log_flush(out, inst, log_lo, col); log_lo = col + 1; }
+        return log_lo;
+    }
+
+    // write columns [c_lo, c_hi] (all inside one block of LOGB columns) of every log row to HBM
+    MPC_PASS void log_flush(const Outputs &out, int inst, int c_lo, int c_hi)
+    {
+        Smem &sm = ex.smem();
+        const size_t T1 = (size_t)c.pb->Nsim + 1;
+        ex.par([&](int lane) {
+            for (int e = lane; e < LOG_ROWS * LOGB; e += NT) {
+                const int row = e / LOGB, cc = (c_hi & ~(LOGB - 1)) + (e & (LOGB - 1));
+                if (cc < c_lo || cc > c_hi) continue;
+                double *dst = row < 12 ? out.z + ((size_t)inst * 12 + row) * T1
+                            : row < 18 ? out.u + ((size_t)inst * 6 + (row - 12)) * T1
+                            : row < 30 ? out.ee_pose + ((size_t)inst * 12 + (row - 18)) * T1
+                            : row < 33 ? out.ee_rpy + ((size_t)inst * 3 + (row - 30)) * T1
+                            : row < 39 ? out.ee_vel + ((size_t)inst * 6 + (row - 33)) * T1
+                                       : out.errors + ((size_t)inst * 7 + (row - 39)) * T1;
+                dst[cc] = sm.logbuf[row][e & (LOGB - 1)];
             }
         });
     }

@@ -229,6 +229,71 @@ __global__ __launch_bounds__(WAVE *NWV, MPCB_WPE) void mpc_rollout_kernel(Proble
     eng.rollout(out, inst, step0, step1);
 }
 
+// Per-simulation summary of Simulator.get_summary (simulator.py:509-547) from the device logs: one wavefront per
+// simulation streams its error rows and per-step statistics once (HBM-bound, coalesced).  out[MPCB_NSUMMARY]:
+//   [0..4] rmse e1..e5  [5..9] itse e1..e5  [10] weighted_rmse  [11] total_sqp_iterations  [12] avg_sqp_iterations
+//   [13] num_failures  [14] max_kkt_residual  [15] total_solver_time  [16] avg_mpc_time  [17] avg_solver_time
+//   [18] avg_integration_time  [19] total_computation_time  [20] total_qp_iterations  [21..23] reserved
+__global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, const InstParams *__restrict__ params, Outputs o,
+                                                           double plant_frac, double *__restrict__ summary)
+{
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= batch) return;
+    const int T1 = Nsim + 1;
+    const double dt = params[inst].dt;
+    double se[5] = {0, 0, 0, 0, 0}, st[5] = {0, 0, 0, 0, 0};
+    for (int c = lane; c < T1; c += WAVE) {
+        const double tk = c * dt;                                    // simulator.py:367
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const double e = o.errors[((size_t)inst * 7 + j) * T1 + c];
+            se[j] += e * e;
+            st[j] += tk * e * e;                                     // :368
+        }
+    }
+    double sq = 0, qp = 0, fail = 0, kkt = 0, tsol = 0;
+    for (int i = lane; i < Nsim; i += WAVE) {
+        const size_t k = (size_t)inst * Nsim + i;
+        sq += o.sqp_iter[k]; qp += o.qp_iter[k]; fail += o.status[k] != 0 ? 1.0 : 0.0;
+        tsol += o.solver_time[k];
+        const double *r = o.residuals + k * 4;
+        kkt = fmax(kkt, fmax(fmax(r[0], r[1]), fmax(r[2], r[3])));    // :402
+    }
+    using X = DevExec<1>;
+    double wsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        se[j] = X::wave_reduce(se[j], X::OpSum());
+        st[j] = X::wave_reduce(st[j], X::OpSum());
+        wsum += params[inst].w_task[j] * se[j];                      // :383-384 (weights 50 each)
+    }
+    sq = X::wave_reduce(sq, X::OpSum()); qp = X::wave_reduce(qp, X::OpSum()); fail = X::wave_reduce(fail, X::OpSum());
+    tsol = X::wave_reduce(tsol, X::OpSum()); kkt = X::wave_reduce(kkt, X::OpMax());
+    if (lane == 0) {
+        double *s = summary + (size_t)inst * MPCB_NSUMMARY;
+        for (int j = 0; j < 5; j++) { s[j] = sqrt(se[j] / T1); s[5 + j] = st[j] * dt; }
+        s[10] = sqrt(wsum / T1);
+        s[11] = sq; s[12] = sq / Nsim; s[13] = fail; s[14] = kkt; s[15] = tsol;
+        // the device times one whole closed-loop step; `plant_frac` of it is booked as the plant update
+        // (simulator.py:224-226 integration_time), the rest as the solve (simulator.py:209-214 mpc_time)
+        s[16] = (1.0 - plant_frac) * tsol / Nsim; s[17] = tsol / Nsim; s[18] = plant_frac * tsol / Nsim; s[19] = tsol;
+        s[20] = qp; s[21] = s[22] = s[23] = 0.0;
+    }
+}
+
+// Diagnostic entry (tests): the device linearisation task_lin on n points, one lane each.
+__global__ void mpc_debug_task_lin_kernel(int n, Robot rb, const InstParams *__restrict__ params, const double *__restrict__ x,
+                                          double *__restrict__ rec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xx[12], out[W2_LIN];
+    for (int j = 0; j < 12; j++) xx[j] = x[(size_t)i * 12 + j];
+    for (int j = 0; j < W2_LIN; j++) out[j] = 0.0;
+    task_lin<true>(rb, params[i], xx, xx + 6, out);
+    for (int j = 0; j < W2_LIN; j++) rec[(size_t)i * W2_LIN + j] = out[j];
+}
+
 // ------------------------------------------------------------------------------------ host
 struct mpcb_handle {
     int device = -1;
@@ -333,7 +398,7 @@ size_t mpcb_result_bytes_per_sim(const mpcb_problem *p)
 {
     if (!p) return 0;
     const size_t T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
-    return (12 + 6 + 12 + 3 + 6) * T1 * sizeof(double) + 3 * S * sizeof(int) + (4 + 1 + 1) * S * sizeof(double);
+    return (12 + 6 + 12 + 3 + 6 + 7) * T1 * sizeof(double) + 3 * S * sizeof(int) + (4 + 1 + 1) * S * sizeof(double);
 }
 
 int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host)
@@ -389,11 +454,6 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         int nw = wpc <= 1 ? 4 : (wpc <= 2 ? 2 : 1);
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) nw = atoi(env);
         h->waves_per_sim = nw;
-        const int lds_bytes = h->pool_doubles * (int)sizeof(double);
-        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        HIPCHK(h, hipFuncSetAttribute((const void *)mpc_rollout_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
     h->ready = true;
     h->next_step = 0;
@@ -410,14 +470,23 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
         return fail(h, MPCB_ESTATE, "step0 must continue the previous rollout (or be 0 to restart)");
     if (step1 <= step0 || step1 > h->pb.Nsim) return fail(h, MPCB_EINVAL, "step range out of bounds");
     if (!o->z || !o->u || !o->ee_pose || !o->ee_rpy || !o->ee_vel || !o->status || !o->sqp_iter || !o->qp_iter ||
-        !o->residuals || !o->cost || !o->solver_time)
+        !o->residuals || !o->cost || !o->solver_time || !o->errors)
         return fail(h, MPCB_EINVAL, "every result array must be provided");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     Outputs out;
     std::memcpy(&out, o, sizeof out);
-    HIPCHK(h, hipEventRecord(h->ev0, s));
     const size_t lds = (size_t)h->pool_doubles * sizeof(double);
+    {
+        // the dynamic-LDS ceiling is a process-wide attribute of the kernel, not of this handle: always raise it to
+        // the largest pool any handle can ask for, right before the launch
+        static const int max_lds = (160 * 1024 - (int)sizeof(Smem) - 64) / 16 * 16;
+        const void *fn = h->waves_per_sim == 8 ? (const void *)mpc_rollout_kernel<8>
+                       : h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
+                       : h->waves_per_sim == 2 ? (const void *)mpc_rollout_kernel<2> : (const void *)mpc_rollout_kernel<1>;
+        HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    }
+    HIPCHK(h, hipEventRecord(h->ev0, s));
     const dim3 grid((unsigned)h->pb.batch);
     if (h->waves_per_sim == 8)
         hipLaunchKernelGGL(mpc_rollout_kernel<8>, grid, dim3(WAVE * 8), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
@@ -500,6 +569,54 @@ int mpcb_debug_workspace(mpcb_handle *h, int inst, double *out, size_t n_doubles
     return MPCB_OK;
 }
 
+int mpcb_summary(mpcb_handle *h, const mpcb_result *o, double plant_time_fraction, double *summary_dev, void *stream)
+{
+    if (!h) return MPCB_EINVAL;
+    if (!h->ready) return fail(h, MPCB_ESTATE, "mpcb_summary before mpcb_setup");
+    if (!o || !summary_dev || !o->errors || !o->status || !o->sqp_iter || !o->qp_iter || !o->residuals || !o->solver_time)
+        return fail(h, MPCB_EINVAL, "mpcb_summary needs the errors, status, iteration, residual and time arrays");
+    if (!(plant_time_fraction >= 0.0 && plant_time_fraction <= 1.0)) return fail(h, MPCB_EINVAL, "plant_time_fraction outside [0,1]");
+    HIPCHK(h, hipSetDevice(h->device));
+    Outputs out;
+    std::memcpy(&out, o, sizeof out);
+    hipLaunchKernelGGL(mpc_summary_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), 0, (hipStream_t)stream, h->pb.batch, h->pb.Nsim,
+                       h->d_params, out, plant_time_fraction, summary_dev);
+    HIPCHK(h, hipGetLastError());
+    return MPCB_OK;
+}
+
+// Diagnostic (tests/test_gpu_parity.py): evaluate the device linearisation (task residual r, dg/dq, dg5/dqdot) at
+// n points; params_host = n parameter records, x_host = n x 12 [q; qdot], rec_host = n x 60 (layout of a G2 record,
+// mpc_layout.h O_R / O_GQ / O_GV).  Not part of include/mpcbatch.h.
+int mpcb_debug_task_lin(mpcb_handle *h, int n, const double *params_host, const double *robot_host, const double *x_host,
+                        double *rec_host)
+{
+    if (!h || n < 1 || !params_host || !robot_host || !x_host || !rec_host) return MPCB_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<InstParams> packed((size_t)n);
+    for (int i = 0; i < n; i++) pack_inst_params(params_host + (size_t)i * MPCB_NPARAM, &packed[(size_t)i]);
+    Robot rb;
+    std::memcpy(&rb, robot_host, sizeof rb);
+    InstParams *dp = nullptr;
+    double *dx = nullptr, *dr = nullptr;
+    int rc = MPCB_OK;
+    if (hipMalloc((void **)&dp, n * sizeof(InstParams)) != hipSuccess || hipMalloc((void **)&dx, (size_t)n * 12 * 8) != hipSuccess ||
+        hipMalloc((void **)&dr, (size_t)n * W2_LIN * 8) != hipSuccess)
+        rc = fail(h, MPCB_ENOMEM, "hipMalloc(debug)");
+    if (rc == MPCB_OK && (hipMemcpy(dp, packed.data(), n * sizeof(InstParams), hipMemcpyHostToDevice) != hipSuccess ||
+                          hipMemcpy(dx, x_host, (size_t)n * 12 * 8, hipMemcpyHostToDevice) != hipSuccess))
+        rc = fail(h, MPCB_EHIP, "hipMemcpy(debug in)");
+    if (rc == MPCB_OK) {
+        hipLaunchKernelGGL(mpc_debug_task_lin_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, n, rb, dp, dx, dr);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(rec_host, dr, (size_t)n * W2_LIN * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(h, MPCB_EHIP, "debug task_lin kernel");
+    }
+    if (dp) (void)hipFree(dp);
+    if (dx) (void)hipFree(dx);
+    if (dr) (void)hipFree(dr);
+    return rc;
+}
+
 int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host,
              const mpcb_result *oh)
 {
@@ -508,8 +625,8 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
     int rc = mpcb_setup(h, p, params_host, robot_host);
     if (rc) return rc;
     const size_t B = (size_t)p->batch, T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
-    const size_t nd[5] = {12 * T1, 6 * T1, 12 * T1, 3 * T1, 6 * T1};
-    const size_t dbl_total = B * (nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + 6 * S);
+    const size_t nd[6] = {12 * T1, 6 * T1, 12 * T1, 3 * T1, 6 * T1, 7 * T1};
+    const size_t dbl_total = B * (nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + nd[5] + 6 * S);
     const size_t int_total = B * 3 * S;
     double *dd = nullptr;
     int *di = nullptr;
@@ -522,6 +639,7 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
     od.ee_pose = pd; pd += B * nd[2];
     od.ee_rpy = pd; pd += B * nd[3];
     od.ee_vel = pd; pd += B * nd[4];
+    od.errors = pd; pd += B * nd[5];
     od.residuals = pd; pd += B * 4 * S;
     od.cost = pd; pd += B * S;
     od.solver_time = pd; pd += B * S;
@@ -531,7 +649,7 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
     if (rc == MPCB_OK) {
         struct { void *dst; const void *src; size_t n; } cp[] = {
             {oh->z, od.z, B * nd[0] * 8}, {oh->u, od.u, B * nd[1] * 8}, {oh->ee_pose, od.ee_pose, B * nd[2] * 8},
-            {oh->ee_rpy, od.ee_rpy, B * nd[3] * 8}, {oh->ee_vel, od.ee_vel, B * nd[4] * 8},
+            {oh->ee_rpy, od.ee_rpy, B * nd[3] * 8}, {oh->ee_vel, od.ee_vel, B * nd[4] * 8}, {oh->errors, od.errors, B * nd[5] * 8},
             {oh->residuals, od.residuals, B * 4 * S * 8}, {oh->cost, od.cost, B * S * 8},
             {oh->solver_time, od.solver_time, B * S * 8}, {oh->status, od.status, B * S * 4},
             {oh->sqp_iter, od.sqp_iter, B * S * 4}, {oh->qp_iter, od.qp_iter, B * S * 4}};

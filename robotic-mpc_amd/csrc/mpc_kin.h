@@ -166,4 +166,30 @@ MPC_HD void plant_log(const Robot &rb, const double *z, double *out33)
     out33[18] = om.x; out33[19] = om.y; out33[20] = om.z;
 }
 
+// Task errors of Simulator.errors (simulator.py:265-344) from one logged pose / velocity column:
+// out7 = [e1, e2, e3, e4, e5, p_task_z, p_ee_y].  Reproduces the reference's e5 literally:
+// v_task = R (v + (w . t_w)) -- a dot product broadcast onto the linear velocity, R not transposed
+// (simulator.py:317) -- unlike the OCP's R^T (v + w x t_w) (prediction_model.py:313).
+MPC_HD void task_errors(const InstParams &P, const Robot &rb, const double *pose12, const double *vel6, double *out7)
+{
+    const double r00 = pose12[3], r01 = pose12[4], r02 = pose12[5], r10 = pose12[6], r11 = pose12[7], r12 = pose12[8],
+                 r20 = pose12[9], r21 = pose12[10], r22 = pose12[11];
+    const double tx = rb.t_ee[0], ty = rb.t_ee[1], tz = rb.t_ee[2];
+    const double twx = r00 * tx + r01 * ty + r02 * tz, twy = r10 * tx + r11 * ty + r12 * tz, twz = r20 * tx + r21 * ty + r22 * tz;  // :309
+    const double X = pose12[0] + twx, Y = pose12[1] + twy, Z = pose12[2] + twz;                                                    // :314
+    const double dotw = vel6[3] * twx + vel6[4] * twy + vel6[5] * twz;
+    const double vty = r10 * (vel6[0] + dotw) + r11 * (vel6[1] + dotw) + r12 * (vel6[2] + dotw);                                   // :317, row 1
+    const double a = P.coeffs[0], b = P.coeffs[1], c = P.coeffs[2], d = P.coeffs[3], e = P.coeffs[4], f = P.coeffs[5];
+    const double nx = 2 * a * X + c * Y + d, ny = 2 * b * Y + c * X + e;
+    const double nn = sqrt(nx * nx + ny * ny + 1.0);
+    const double S = a * X * X + b * Y * Y + c * X * Y + d * X + e * Y + f;                                                        // :330
+    out7[0] = S - Z;                                                   // e1 = g1            :331,337
+    out7[1] = 1.0 - (nx / nn * r02 + ny / nn * r12 + (-1.0 / nn) * r22);   // e2 = 1 - n . z_task :332,338
+    out7[2] = r01;                                                     // e3 = y_task[0]     :333,339
+    out7[3] = P.px_ref - X;                                            // e4                 :334,340
+    out7[4] = P.vy_ref - vty;                                          // e5                 :335,341
+    out7[5] = Z;                                                       // p_task_z           :342
+    out7[6] = pose12[1];                                               // p_ee_y             :344
+}
+
 }  // namespace mpcb

@@ -94,10 +94,12 @@ struct InstParams {
     double wcv[6], q0[6], qdot0[6], qmin[6], qmax[6], umin[6], umax[6];
     double coeffs[6];   // a b c d e f   (surface.py:14-17)
     double w_task[5];   // trajectory_optimizer.py:44-48
-    double pad1;
+    double lm;          // acados levenberg_marquardt: dt*lm*I on the stage Hessians, lm*I on the terminal one
     // derived on the host in C (prediction_model.py:87-115, 322-326)
     double a12[6], a22[6], b1[6], b2[6];
     double cq[6];       // qddot gain (1-a22)/Ts
+    // acados nlp_solver_tol_eq / _ineq / _comp (`tol` above is nlp_solver_tol_stat)
+    double tol_eq, tol_ineq, tol_comp, pad2;
 };
 
 // Batch-uniform problem description (== mpcb_problem).
@@ -126,6 +128,7 @@ struct Outputs {
     double *residuals; // [batch][Nsim][4]
     double *cost;      // [batch][Nsim]
     double *solver_time; // [batch][Nsim] seconds (device realtime counter)
+    double *errors;    // [batch][7][Nsim+1]  e1..e5, p_task_z, p_ee_y (simulator.py:265-344)
 };
 
 // One instance's workspace: five stage-major group arrays + persistent scalars.
@@ -153,6 +156,9 @@ MPC_HD Ws ws_carve(double *base, int N)
     return w;
 }
 
+// rows of the per-step trajectory log: z 12 | u 6 | ee_pose 12 | ee_rpy 3 | ee_vel 6 | errors 7
+constexpr int LOG_ROWS = 46, LOGB = 8;
+
 // Static LDS working set of one simulation (workgroup); the chunk pool follows it (dynamic LDS).
 // Every array is 16-byte aligned: the compiler merges neighbouring doubles into ds_read/write_b128,
 // and a b128 DS access off its 16-byte alignment is replayed at ~64 cycles (MI355X_MICROARCH.md, LDS).
@@ -173,7 +179,10 @@ struct Smem {
     alignas(16) double red[8][NWV_MAX];   // one partial per wavefront (Ex::put_* / get_*)
     alignas(16) double xhat[12];    // current plant state (feedback, simulator.py:206)
     alignas(16) double u0[6];
-    alignas(16) double logv[40];
+    alignas(16) double logv[48];    // [0..20] pose, rpy, J qdot | [24..35] next plant state | [36..42] task errors
+    // log columns wait here until LOGB of them leave as contiguous runs (one 64-byte run per row and flush
+    // instead of one 8-byte store per row and step)
+    alignas(16) double logbuf[LOG_ROWS][LOGB];
 };
 
 // Chunk pool sizes (doubles).  The widest pass needs ~500 doubles per stage (+1 halo stage).

@@ -30,7 +30,19 @@ RESULT_FIELDS = (
     ("ee_rpy", "f8", lambda S, T: (3, T)), ("ee_vel", "f8", lambda S, T: (6, T)),
     ("status", "i4", lambda S, T: (S,)), ("sqp_iter", "i4", lambda S, T: (S,)), ("qp_iter", "i4", lambda S, T: (S,)),
     ("residuals", "f8", lambda S, T: (S, 4)), ("cost", "f8", lambda S, T: (S,)), ("solver_time", "f8", lambda S, T: (S,)),
+    ("errors", "f8", lambda S, T: (7, T)),
 )
+ERROR_ROWS = ("e1", "e2", "e3", "e4", "e5", "p_task_z", "p_ee_y")   # rows of `errors` (simulator.py:337-344)
+NSUMMARY = 24
+# columns of the mpcb_summary record (include/mpcbatch.h)
+SUMMARY_COLS = ("rmse_e1", "rmse_e2", "rmse_e3", "rmse_e4", "rmse_e5", "itse_e1", "itse_e2", "itse_e3", "itse_e4", "itse_e5",
+                "weighted_rmse", "total_sqp_iterations", "avg_sqp_iterations", "num_failures", "max_kkt_residual",
+                "total_solver_time", "avg_mpc_time", "avg_solver_time", "avg_integration_time", "total_computation_time",
+                "total_qp_iterations")
+# share of a device-timed closed-loop step reported as the plant update (integration_time, simulator.py:224-226):
+# the plant step, FK / J qdot logging and the error column against the whole step, measured with the profile build
+# (profiles/r01_device_breakdown.txt: plant+log 6 of 800 us)
+PLANT_TIME_FRACTION = 0.0075
 
 
 class MpcbProblem(C.Structure):
@@ -40,7 +52,8 @@ class MpcbProblem(C.Structure):
 
 class MpcbResult(C.Structure):
     _fields_ = [("z", _dp), ("u", _dp), ("ee_pose", _dp), ("ee_rpy", _dp), ("ee_vel", _dp), ("status", _ip),
-                ("sqp_iter", _ip), ("qp_iter", _ip), ("residuals", _dp), ("cost", _dp), ("solver_time", _dp)]
+                ("sqp_iter", _ip), ("qp_iter", _ip), ("residuals", _dp), ("cost", _dp), ("solver_time", _dp),
+                ("errors", _dp)]
 
 
 class EngineError(RuntimeError):
@@ -49,7 +62,7 @@ class EngineError(RuntimeError):
 
 _EXPORTS = ("mpcb_version", "mpcb_device_count", "mpcb_create", "mpcb_destroy", "mpcb_last_error",
             "mpcb_workspace_bytes", "mpcb_result_bytes_per_sim", "mpcb_setup", "mpcb_rollout", "mpcb_sync",
-            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_run")
+            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_summary", "mpcb_run")
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -85,6 +98,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.mpcb_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.mpcb_kernel_info.argtypes = [C.c_void_p] + [_ip] * 4
     lib.mpcb_run.argtypes = [C.c_void_p, C.POINTER(MpcbProblem), _dp, _dp, C.POINTER(MpcbResult)]
+    lib.mpcb_summary.argtypes = [C.c_void_p, C.POINTER(MpcbResult), C.c_double, _dp, C.c_void_p]
+    lib.mpcb_launch_info.argtypes = [C.c_void_p, _ip, _ip]
+    if hasattr(lib, "mpcb_debug_task_lin"):
+        lib.mpcb_debug_task_lin.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
     return lib
 
 
@@ -183,6 +200,31 @@ class MpcBatchEngine:
 
     def sync(self):
         self._check(self.lib.mpcb_sync(self._h), "mpcb_sync")
+
+    def summary(self, bufs, stream: Optional[int] = None):
+        """Per-simulation summary record [batch, NSUMMARY] (device tensor) of a finished rollout --
+        Simulator.metrics / solver_stats / timings / get_summary for the whole batch in one launch."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = torch.empty((self._pb.batch, NSUMMARY), dtype=torch.float64, device=torch.device("cuda", self.device))
+        r = self._result_struct(bufs)
+        self._check(self.lib.mpcb_summary(self._h, C.byref(r), C.c_double(PLANT_TIME_FRACTION),
+                                          C.cast(C.c_void_p(out.data_ptr()), _dp), C.c_void_p(stream)), "mpcb_summary")
+        return out
+
+    def debug_task_lin(self, cfgs: Sequence[Dict], chain, x: np.ndarray) -> np.ndarray:
+        """Diagnostic: the device linearisation at points x[i] = [q; qdot] with the parameters of cfgs[i];
+        returns [n, 60] records laid out like a G2 stage record (r 0..4, dg/dq 24..53, dg5/dqdot 54..59)."""
+        n = len(cfgs)
+        params = packing.pack_batch(cfgs)
+        robot = np.ascontiguousarray(chain.packed(cfgs[0]["t_ee"]), dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(n, 12)
+        rec = np.zeros((n, 60))
+        self._check(self.lib.mpcb_debug_task_lin(self._h, n, params.ctypes.data_as(_dp), robot.ctypes.data_as(_dp),
+                                                 x.ctypes.data_as(_dp), rec.ctypes.data_as(_dp)), "mpcb_debug_task_lin")
+        return rec
 
     def kernel_ms(self) -> float:
         ms = C.c_float(0)

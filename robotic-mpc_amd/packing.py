@@ -6,17 +6,19 @@ from typing import Dict, Sequence
 
 import numpy as np
 
-NPARAM = 64
+NPARAM = 72
 
 
 def pack_params(cfg: Dict) -> np.ndarray:
-    """One instance: resolved config (config.resolve_config) -> 64 doubles."""
+    """One instance: resolved config (config.resolve_config) -> NPARAM doubles."""
     p = np.zeros(NPARAM, dtype=np.float64)
     p[0] = cfg["dt"]; p[1] = cfg["tol"]; p[2] = cfg["qp_tol"]; p[3] = cfg["w_u"]; p[4] = cfg["w_qddot"]
     p[5] = cfg["px_ref"]; p[6] = cfg["vy_ref"]; p[7] = float(cfg.get("plant_integrator", 0))
     p[8:14] = cfg["wcv"]; p[14:20] = cfg["q0"]; p[20:26] = cfg["qdot0"]
     p[26:32] = cfg["qmin"]; p[32:38] = cfg["qmax"]; p[38:44] = cfg["umin"]; p[44:50] = cfg["umax"]
     p[50:56] = cfg["coeffs"]; p[56:61] = cfg["w_task"]
+    p[61] = cfg.get("tol_eq", 0.0); p[62] = cfg.get("tol_ineq", 0.0); p[63] = cfg.get("tol_comp", 0.0)
+    p[64] = cfg.get("levenberg_marquardt", 0.0)
     return p
 
 

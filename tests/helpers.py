@@ -143,8 +143,14 @@ def oracle_runner(cfgs, chain):
     from oracle import orc
 
     rb = orc.make_robot(chain, cfgs[0]["t_ee"]) if cfgs else None
+    from robotic_mpc_amd import analysis
+
     recs = [orc.run(rb, orc.make_params(c)) for c in cfgs]
-    keys = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "status", "sqp_iter", "qp_iter", "residuals", "cost", "solver_time")
+    for r, c in zip(recs, cfgs):   # the engine logs the task errors with every column; here they come from the numpy analysis
+        e = analysis.compute_errors(r["ee_pose"], r["ee_vel"], c["coeffs"], c["t_ee"], c["px_ref"], c["vy_ref"])
+        r["errors"] = np.stack([e[k] for k in ("e1", "e2", "e3", "e4", "e5", "p_task_z", "p_ee_y")])
+    keys = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "status", "sqp_iter", "qp_iter", "residuals", "cost", "solver_time",
+            "errors")
     return {k: np.stack([r[k] for r in recs]) for k in keys}
 
 

@@ -31,13 +31,13 @@ def test_header_symbols_are_exported(lib):
 def test_version_and_sizes(lib):
     from robotic_mpc_amd import engine, packing
 
-    assert lib.mpcb_version() == 100
+    assert lib.mpcb_version() == 200
     pb = engine.MpcbProblem(256, 100, 600, 1, 100, 50, 0, 0)
     ws = lib.mpcb_workspace_bytes(C.byref(pb))
     assert 256 * 101 * 600 * 8 < ws < 256 * 101 * 1200 * 8  # a few hundred doubles per stage
     per_sim = lib.mpcb_result_bytes_per_sim(C.byref(pb))
-    assert per_sim == (39 * 601 + 6 * 600) * 8 + 3 * 600 * 4
-    assert packing.NPARAM == 64
+    assert per_sim == (46 * 601 + 6 * 600) * 8 + 3 * 600 * 4
+    assert packing.NPARAM == 72
     bad = engine.MpcbProblem(0, 100, 600, 1, 100, 50, 0, 0)
     assert lib.mpcb_workspace_bytes(C.byref(bad)) == 0
 
@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     from robotic_mpc_amd import engine
 
     assert C.sizeof(engine.MpcbProblem) == 32
-    assert C.sizeof(engine.MpcbResult) == 11 * 8
+    assert C.sizeof(engine.MpcbResult) == 12 * 8
 
 
 @pytest.mark.skipif(__import__("conftest").has_gpu(), reason="checks the no-device behaviour")
@@ -85,7 +85,8 @@ def test_param_packing_layout():
 
     cfg = config.resolve_config(config.base_params())
     p = packing.pack_params(cfg)
-    assert p.shape == (64,) and p[0] == 0.01 and p[2] == 1e-8 and p[1] == 1e-6
+    assert p.shape == (72,) and p[0] == 0.01 and p[2] == 1e-8 and p[1] == 1e-6
+    assert p[61] == p[62] == p[63] == 1e-6 and p[64] == 0.0
     np.testing.assert_array_equal(p[8:14], [200.0] * 6)
     np.testing.assert_array_equal(p[14:20], cfg["q0"])
     np.testing.assert_array_equal(p[38:44], cfg["umin"])

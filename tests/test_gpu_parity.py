@@ -161,7 +161,7 @@ def test_call_order_and_argument_errors(eng, ur10):
     with pytest.raises(engine.EngineError, match="bounds"):
         e2.rollout(bufs, 0, pb.Nsim + 1)
     bad = engine.MpcbProblem(1, 0, 5, 1, 100, 50, 0, 0)
-    z = np.zeros(64)
+    z = np.zeros(128)
     assert e2.lib.mpcb_setup(e2._h, C.byref(bad), z.ctypes.data_as(engine._dp), z.ctypes.data_as(engine._dp)) == -1
     e2.close()
 
