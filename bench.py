@@ -4,18 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One bench "step" = one pass of the hot path over one batch: `run_all` of BASELINE.json
-configs[1] -- 256 UR10 simulations, prediction horizon N=100, dt=0.01, 6 s (600 closed-loop MPC
-steps each), SQP_RTI, flat surface, seeded q_0 jitter -- i.e. 153 600 MPC steps per GPU per
-bench step.  Weak scaling: every rank (one per GPU) runs its own batch of 256; the only
-exchange is the gather of the result logs to rank 0 (RCCL), inside the timed region.
-Parameters are uploaded before the timed region; results stay in HBM (torch tensors).
+One bench "step" = one pass of the hot path over one batch, as BASELINE.md section 4 defines the metric
+(wall of mpcb_run incl. H2D params and D2H/gather of results): for BASELINE.json configs[1] -- 256 UR10
+simulations, prediction horizon N=100, dt=0.01, 6 s (600 closed-loop MPC steps each), SQP_RTI, flat surface,
+seeded q_0 jitter, i.e. 153 600 MPC steps per GPU per bench step -- the timed region holds
+
+    parameter packing + upload (mpcb_setup)  ->  rollout kernel  ->  summary kernel  ->
+    [N > 1: gather of every result array to rank 0, RCCL on the device tensors]  ->  D2H of all logs (rank 0: of all ranks)
+
+The synthetic configs are resident in host memory and the device buffers are allocated before the timed region.
+The kernel-only rate (HIP events around the rollout launch on its stream) is reported beside it as
+`kernel_steps_per_s`; `roofline` is computed from that kernel time.  Weak scaling: every rank (one per GPU) runs
+its own batch of 256; the only exchange is the final gather.
+
+The CPU baseline (oracle port, `-O3 -march=native`, built on this host) is measured in a child process that
+is started BEFORE this process touches torch / HIP (no fork of a process with a live HIP runtime) and that
+waits for the GPU measurement to finish before it starts its own (the two never compete for the host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -52,51 +63,72 @@ def bytes_per_mpc_step(N: int) -> int:
 
 def pmc_traffic(batch, N, Nsim, solver):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r01_pmc_summary.json, written by scripts/profile_gpu.sh); None when absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    (profiles/r02_pmc_summary.json, written by scripts/profile_gpu.sh); None when absent or when it was
+    taken on another workload.  The summary names the commit it was profiled at."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as f:
             d = json.load(f)
         if (d.get("batch"), d.get("N"), d.get("Nsim"), d.get("solver")) == (batch, N, Nsim, solver):
-            return float(d["hbm_bytes_per_launch"]), "profiles/r01_pmc_summary.json (separate --pmc passes)"
+            return float(d["hbm_bytes_per_launch"]), f"profiles/r02_pmc_summary.json (separate --pmc passes, profiled_at_commit {d.get('commit', '?')})"
     except (OSError, ValueError, KeyError):
         pass
     return None, None
 
 
-def cpu_baseline(cfgs, chain, budget_s: float = 20.0):
-    """Oracle (plain-C port of the reference algorithm) on the host cores, bounded sample."""
-    from oracle import orc
+# ------------------------------------------------------------------------------------------- CPU baseline (child)
+def cpu_baseline_main(argv):
+    """Child-process entry: `bench.py --cpu-baseline-child batch N sim_time solver budget_s`.  Builds the oracle
+    with -O3 -march=native on THIS host and times it on a bounded sample of the bench workload.  Prints JSON."""
+    batch, N, sim_time, solver, budget = int(argv[0]), int(argv[1]), float(argv[2]), argv[3], float(argv[4])
+    import tempfile
 
-    orc.build()
+    sys.stdin.readline()      # the parent says "go" once its GPU measurement is over: the two never share the host cores
+
+    from oracle import orc
+    from robotic_mpc_amd import robots
+
+    flags = ["-O3", "-march=native", "-ffp-contract=off"]
+    lib = os.path.join(tempfile.gettempdir(), f"libmpc_oracle_native_{os.getpid()}.so")
+    subprocess.check_call(["gcc", *flags, "-fPIC", "-std=c11", "-shared", "-o", lib, os.path.join(ROOT, "oracle", "mpc_oracle.c"), "-lm"])
+    orc._LIB_PATH = lib
+    orc._lib = None
+    chain = robots.builtin_chain("ur10")
+    cfgs = workload_configs(batch, N, sim_time, seed=0, solver=solver)
     rb = orc.make_robot(chain)
     Nsim = cfgs[0]["Nsim"]
-    # 1 thread, like the reference's single-threaded acados
     t0 = time.time()
     done = 0
-    for c in cfgs:
+    for c in cfgs:     # 1 thread, like the reference's single-threaded acados
         orc.run(rb, orc.make_params(c))
         done += 1
-        if time.time() - t0 > budget_s / 2 or done >= 4:
+        if time.time() - t0 > budget / 2 or done >= 8:
             break
     el = time.time() - t0
-    one = done * Nsim / el
-    out = {"value": one, "unit": "MPC-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{done} of the {len(cfgs)} simulations x {Nsim} steps, oracle/libmpc_oracle.so, 1 thread"}
-    # all host cores: independent simulations in a process pool (reported as extra fields)
-    try:
-        import multiprocessing as mp
+    out = {"value": done * Nsim / el, "unit": "MPC-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{done} of the {len(cfgs)} simulations x {Nsim} steps of the bench workload, oracle/mpc_oracle.c "
+                     f"(dense C restatement of the reference algorithm) built here with gcc {' '.join(flags)}, 1 thread",
+           "flags": " ".join(flags)}
+    import multiprocessing as mp
 
-        ncpu = min(os.cpu_count() or 1, 16)
-        sample = cfgs[: max(ncpu, 1)]
-        t0 = time.time()
-        with mp.get_context("fork").Pool(ncpu) as pool:
-            pool.map(_oracle_one, [(chain, c) for c in sample])
-        el = time.time() - t0
-        out.update({"value_all_cores": len(sample) * Nsim / el, "cores_all": ncpu})
-    except Exception as e:  # pragma: no cover
-        out["all_cores_error"] = repr(e)
-    return out
+    ncpu = min(os.cpu_count() or 1, 16)
+    sample = cfgs[:ncpu]
+    t0 = time.time()
+    with mp.get_context("fork").Pool(ncpu, initializer=_oracle_init, initargs=(lib,)) as pool:
+        pool.map(_oracle_one, [(chain, c) for c in sample])
+    out.update({"value_all_cores": len(sample) * Nsim / (time.time() - t0), "cores_all": ncpu})
+    try:
+        os.unlink(lib)
+    except OSError:
+        pass
+    print("CPU_BASELINE " + json.dumps(out), flush=True)
+
+
+def _oracle_init(lib):
+    from oracle import orc
+
+    orc._LIB_PATH = lib
+    orc._lib = None
 
 
 def _oracle_one(args):
@@ -107,7 +139,29 @@ def _oracle_one(args):
     return 0
 
 
+def start_cpu_baseline(args):
+    """Launch the child BEFORE torch / HIP are touched; its result is collected after the GPU measurement."""
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(args.batch), str(args.horizon),
+                             str(args.sim_time), args.solver, "20"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+
+
+def finish_cpu_baseline(proc):
+    try:
+        out, err = proc.communicate("go\n", timeout=240)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        return {"error": "cpu baseline child timed out"}
+    for line in out.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    return {"error": "cpu baseline child failed", "stderr": err[-400:]}
+
+
+# ------------------------------------------------------------------------------------------- main
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_main(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -117,19 +171,23 @@ def main():
     ap.add_argument("--sim-time", type=float, default=6.0)
     ap.add_argument("--solver", default="SQP_RTI")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true", help="time the rollout alone (parameters resident, results stay in HBM)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (rehearsal of the "
                     "multi-rank control flow on a box with fewer GPUs than ranks: tensors are gathered via the host)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    from robotic_mpc_amd import engine, robots
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_proc = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_proc = start_cpu_baseline(args)      # before the first torch / HIP call of this process
+
+    import torch
+    import torch.distributed as dist
+
+    from robotic_mpc_amd import distributed as dmod, engine, robots
+
     if args.gpus > 1 or world > 1:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU (torch.distributed.run), WORLD_SIZE={world}")
@@ -137,6 +195,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "gloo":   # rehearsal: ranks may share a GPU
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            os.environ["LOCAL_RANK"] = str(local_rank)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -148,9 +207,9 @@ def main():
     chain = robots.builtin_chain("ur10")
     cfgs = workload_configs(args.batch, args.horizon, args.sim_time, seed=rank, solver=args.solver)
     eng = engine.MpcBatchEngine(local_rank)
-    pb = eng.setup(cfgs, chain)            # parameters resident in HBM before the timed region
+    pb = eng.setup(cfgs, chain)            # sizes the workspace (allocation is not part of a pass)
     bufs = eng.alloc_results(pb)
-    gather_note = "n/a"
+    sizes = [args.batch] * world
 
     def barrier():
         if world > 1:
@@ -158,31 +217,30 @@ def main():
         torch.cuda.synchronize()
 
     def one_pass():
-        nonlocal gather_note
-        eng.rollout(bufs, 0, pb.Nsim)  # step0 = 0 restarts every simulation from its initial state
-        if world > 1 and not args.no_gather:
-            try:
-                for name in ("z", "u", "status", "cost"):
-                    t = bufs[name] if args.backend == "nccl" else bufs[name].cpu()
-                    lst = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-                    dist.gather(t, lst, dst=0)
-                gather_note = ("rccl" if args.backend == "nccl" else "gloo (via host)") + " gather of z,u,status,cost to rank 0"
-            except Exception as e:  # keep the measurement alive if the collective is unavailable
-                gather_note = f"gather failed: {e!r}"
+        """mpcb_run as BASELINE.md section 4 defines it; returns the host arrays on rank 0."""
+        if args.kernel_only:
+            eng.rollout(bufs, 0, pb.Nsim)
+            return None
+        eng.setup(cfgs, chain)             # pack + upload the parameter records (H2D)
+        eng.rollout(bufs, 0, pb.Nsim)      # step0 = 0 restarts every simulation from its initial state
+        local = dict(bufs)
+        local["summary"] = eng.summary(bufs)
+        if world > 1:
+            return dmod.gather_to_root(local, sizes)          # product path of run_all: device tensors -> RCCL -> one D2H
+        return {k: dmod.to_host(v) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
 
     for _ in range(args.warmup):
         one_pass()
     barrier()
     kernel_ms = []
+    host = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_pass()
-        if world == 1:
-            kernel_ms.append(eng.kernel_ms())  # HIP events on the launch stream (syncs on the kernel)
-    barrier()
+        host = one_pass()
+        kernel_ms.append(eng.kernel_ms())  # HIP events on the launch stream (the pass has already waited for the kernel,
+    barrier()                              # except with --kernel-only, where this wait is the only sync)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        kernel_ms.append(eng.kernel_ms())
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -201,6 +259,14 @@ def main():
     info = eng.kernel_info()
     geo = eng.launch_info()
     traffic, traffic_src = pmc_traffic(args.batch, pb.N, pb.Nsim, args.solver)
+    if args.kernel_only:
+        region = "rollout kernel only (parameters resident, results left in HBM)"
+    elif world > 1:
+        region = ("per rank: pack+upload params (mpcb_setup) -> rollout -> summary kernel -> "
+                  f"{'RCCL' if args.backend == 'nccl' else 'gloo (via host)'} gather of all {len(bufs) + 1} result arrays to rank 0 -> D2H on rank 0")
+    else:
+        region = "pack+upload params (mpcb_setup) -> rollout -> summary kernel -> D2H of all result arrays (pinned)"
+    d2h_mb = None if host is None else sum(v.nbytes for v in host.values()) / 1e6
 
     line = {
         "metric": "MPC-steps/sec (whole node), UR10 N=100 dt=0.01 batch; 1/2/4/8 GPU",
@@ -210,7 +276,9 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: batch={args.batch} UR10 sims per GPU, N={pb.N}, dt=0.01, "
                                f"{pb.Nsim} closed-loop steps, {args.solver}, flat surface, q_0 jitter U(-0.1,0.1) rng({rank})",
                    "batch_per_gpu": args.batch, "horizon": pb.N, "closed_loop_steps": pb.Nsim, "solver": args.solver,
-                   "parallelism": f"{world} GPU x {args.batch} workgroups (one simulation each) x {geo['waves_per_sim']} wavefronts", "gather": gather_note,
+                   "parallelism": f"{world} GPU x {args.batch} workgroups (one simulation each) x {geo['waves_per_sim']} wavefronts",
+                   "timed_region": region, "host_bytes_per_pass_MB": d2h_mb,
+                   "kernel_steps_per_s": steps_per_pass / avg_kernel_s,
                    "mean_qp_iters_per_step": qp_iters, "qp_iter_histogram_rank0": qp_hist,
                    "ipm_iterations_per_sec": value * qp_iters, "solver_failures": failures},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -222,11 +290,8 @@ def main():
                      "fp64_valu_frac": flops_step * steps_per_pass / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "scratch_bytes": info["scratch_bytes"]},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfgs, chain)
-    elif rank == 0:
-        line["cpu_baseline"] = None
     if rank == 0:
+        line["cpu_baseline"] = finish_cpu_baseline(cpu_proc) if cpu_proc is not None else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -93,9 +93,11 @@ typedef struct {
     int *qp_iter;        /* [batch][Nsim]    interior-point iterations   */
     double *residuals;   /* [batch][Nsim][4] stat, eq, ineq, comp        */
     double *cost;        /* [batch][Nsim]                                */
-    double *solver_time; /* [batch][Nsim]    seconds on the device (one whole closed-loop step) */
+    double *solver_time; /* [batch][Nsim]    device seconds of solver.solve() (simulator.py:209-214,220)  */
     double *errors;      /* [batch][7][T1]   e1..e5, p_task_z, p_ee_y of Simulator.errors (simulator.py:265-344),
                                              computed with the log column on the device                  */
+    double *plant_time;  /* [batch][Nsim]    device seconds of the plant step + FK / J qdot / error logging
+                                             (integration_time, simulator.py:224-226)                    */
 } mpcb_result;
 
 #define MPCB_NSUMMARY 24      /* doubles per simulation written by mpcb_summary, layout below */
@@ -143,9 +145,9 @@ int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes);
  *   [0..4] rmse_e1..e5  [5..9] itse_e1..e5  [10] weighted_rmse  [11] total_sqp_iterations  [12] avg_sqp_iterations
  *   [13] num_failures  [14] max_kkt_residual  [15] total_solver_time  [16] avg_mpc_time  [17] avg_solver_time
  *   [18] avg_integration_time  [19] total_computation_time  [20] total_qp_iterations  [21..23] reserved.
- * The device times a whole closed-loop step; `plant_time_fraction` in [0,1] of it is reported as the plant update
- * (integration_time, simulator.py:224-226) and the rest as the solve (mpc_time, simulator.py:209-214).  Asynchronous. */
-int mpcb_summary(mpcb_handle *h, const mpcb_result *out_dev, double plant_time_fraction, double *summary_dev, void *stream);
+ * mpc_time and solver_time are both the device time of the solve (no Python call overhead exists here),
+ * integration_time is `plant_time`.  Asynchronous on `stream`. */
+int mpcb_summary(mpcb_handle *h, const mpcb_result *out_dev, double *summary_dev, void *stream);
 
 /* Convenience for callers without device buffers of their own: setup + rollout(0,Nsim) +
  * copy-back into HOST arrays `out_host`. */

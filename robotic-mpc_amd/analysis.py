@@ -105,3 +105,44 @@ def compute_data(z, u, ee_pose, wcv, dt, px_ref, vy_ref, N) -> Dict:
     qddot_fd[:, -1] = qddot_fd[:, -2]                       # :474
     return {"time": np.arange(q.shape[1]) * dt, "q": q, "qdot": qdot, "qddot": qddot, "qddot_fd": qddot_fd, "u": u,
             "ee_pose": ee_pose, "px_ref": px_ref, "vy_ref": vy_ref, "N": N}
+
+
+ERROR_ROWS = ("e1", "e2", "e3", "e4", "e5", "p_task_z", "p_ee_y")
+
+
+def errors_rows(errors: Dict[str, np.ndarray]) -> np.ndarray:
+    """The dict of simulator.py:337-344 as the [7, T1] array of mpcb_result.errors."""
+    return np.stack([np.asarray(errors[k]) for k in ERROR_ROWS])
+
+
+def errors_dict(rows: np.ndarray) -> Dict[str, np.ndarray]:
+    return {k: rows[i] for i, k in enumerate(ERROR_ROWS)}
+
+
+def batch_summary(errors, sqp_iter, qp_iter, status, residuals, solver_time, plant_time, dt, w_task=None) -> np.ndarray:
+    """Vectorised Simulator.metrics / solver_stats / timings / get_summary (simulator.py:347-448, 509-547) for a
+    whole bucket at once: arrays [B, ...] -> [B, 24] with the column layout of mpcb_summary (include/mpcbatch.h).
+    The host mirror of the device summary kernel (used when a runner delivers no summary, and to check the kernel)."""
+    e = np.asarray(errors)[:, :5, :]                       # [B,5,T1]
+    B, _, T1 = e.shape
+    dt = np.broadcast_to(np.asarray(dt, dtype=np.float64), (B,))
+    w = np.full((B, 5), TASK_WEIGHT) if w_task is None else np.broadcast_to(np.asarray(w_task, dtype=np.float64), (B, 5))
+    e2 = e * e
+    t = np.arange(T1)[None, None, :] * dt[:, None, None]   # :367
+    out = np.zeros((B, 24))
+    out[:, 0:5] = np.sqrt(e2.mean(axis=2))                 # :375-379
+    out[:, 5:10] = (t * e2).sum(axis=2) * dt[:, None]      # :368-369
+    out[:, 10] = np.sqrt((w[:, :, None] * e2).sum(axis=1).mean(axis=1))   # :383-384
+    S = np.asarray(sqp_iter).shape[1]
+    out[:, 11] = np.asarray(sqp_iter).sum(axis=1)
+    out[:, 12] = out[:, 11] / S
+    out[:, 13] = (np.asarray(status) != 0).sum(axis=1)
+    out[:, 14] = np.asarray(residuals).max(axis=(1, 2))
+    tsol, tpl = np.asarray(solver_time).sum(axis=1), np.asarray(plant_time).sum(axis=1)
+    out[:, 15] = tsol
+    out[:, 16] = tsol / S
+    out[:, 17] = tsol / S
+    out[:, 18] = tpl / S
+    out[:, 19] = tsol + tpl
+    out[:, 20] = np.asarray(qp_iter).sum(axis=1)
+    return out

@@ -64,7 +64,7 @@ _QP_TOLS = ("qp_solver_tol_stat", "qp_solver_tol_eq", "qp_solver_tol_ineq", "qp_
 # QP method (Mehrotra IPM on the sparse OCP-QP, HPIPM semantics); these are accepted without effect.
 _ACCEPTED_NOOP = {
     "qp_solver_cond_N", "print_level", "N_horizon", "tf", "qp_solver_cond_ric_alg", "qp_solver_ric_alg",
-    "ext_fun_compile_flags",
+    "ext_fun_compile_flags", "regularize_method",   # (regularize_method: only NO_REGULARIZE passes the check below)
 }
 _QP_SOLVERS_EQUIVALENT = ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM")
 

@@ -1660,6 +1660,8 @@ struct Engine {
                 if (lane < NX) sm.xhat[lane] = sm.logv[24 + lane];
             });
             log_lo = ex.uni(log_state(out, inst, i + 1, log_lo));
+            const double t2 = ex.clock();
+            ex.par([&](int lane) { if (lane == 0) out.plant_time[sb + i] = t2 - t1; });
             PROF_ADD(PF_PLANT, tp);
         }
         if (log_lo <= step1) log_flush(out, inst, log_lo, step1);   // the columns of a partly filled block

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVE *NWV, MPCB_WPE) void mpc_rollout_kernel(Proble
 //   [13] num_failures  [14] max_kkt_residual  [15] total_solver_time  [16] avg_mpc_time  [17] avg_solver_time
 //   [18] avg_integration_time  [19] total_computation_time  [20] total_qp_iterations  [21..23] reserved
 __global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, const InstParams *__restrict__ params, Outputs o,
-                                                           double plant_frac, double *__restrict__ summary)
+                                                           double *__restrict__ summary)
 {
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= batch) return;
@@ -251,11 +251,11 @@ __global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, 
             st[j] += tk * e * e;                                     // :368
         }
     }
-    double sq = 0, qp = 0, fail = 0, kkt = 0, tsol = 0;
+    double sq = 0, qp = 0, fail = 0, kkt = 0, tsol = 0, tpl = 0;
     for (int i = lane; i < Nsim; i += WAVE) {
         const size_t k = (size_t)inst * Nsim + i;
         sq += o.sqp_iter[k]; qp += o.qp_iter[k]; fail += o.status[k] != 0 ? 1.0 : 0.0;
-        tsol += o.solver_time[k];
+        tsol += o.solver_time[k]; tpl += o.plant_time[k];
         const double *r = o.residuals + k * 4;
         kkt = fmax(kkt, fmax(fmax(r[0], r[1]), fmax(r[2], r[3])));    // :402
     }
@@ -268,15 +268,14 @@ __global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, 
         wsum += params[inst].w_task[j] * se[j];                      // :383-384 (weights 50 each)
     }
     sq = X::wave_reduce(sq, X::OpSum()); qp = X::wave_reduce(qp, X::OpSum()); fail = X::wave_reduce(fail, X::OpSum());
-    tsol = X::wave_reduce(tsol, X::OpSum()); kkt = X::wave_reduce(kkt, X::OpMax());
+    tsol = X::wave_reduce(tsol, X::OpSum()); tpl = X::wave_reduce(tpl, X::OpSum()); kkt = X::wave_reduce(kkt, X::OpMax());
     if (lane == 0) {
         double *s = summary + (size_t)inst * MPCB_NSUMMARY;
         for (int j = 0; j < 5; j++) { s[j] = sqrt(se[j] / T1); s[5 + j] = st[j] * dt; }
         s[10] = sqrt(wsum / T1);
         s[11] = sq; s[12] = sq / Nsim; s[13] = fail; s[14] = kkt; s[15] = tsol;
-        // the device times one whole closed-loop step; `plant_frac` of it is booked as the plant update
-        // (simulator.py:224-226 integration_time), the rest as the solve (simulator.py:209-214 mpc_time)
-        s[16] = (1.0 - plant_frac) * tsol / Nsim; s[17] = tsol / Nsim; s[18] = plant_frac * tsol / Nsim; s[19] = tsol;
+        // mpc_time (simulator.py:209-214) = the device time of the solve, integration_time (:224-226) = plant step + logging
+        s[16] = tsol / Nsim; s[17] = tsol / Nsim; s[18] = tpl / Nsim; s[19] = tsol + tpl;
         s[20] = qp; s[21] = s[22] = s[23] = 0.0;
     }
 }
@@ -398,7 +397,7 @@ size_t mpcb_result_bytes_per_sim(const mpcb_problem *p)
 {
     if (!p) return 0;
     const size_t T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
-    return (12 + 6 + 12 + 3 + 6 + 7) * T1 * sizeof(double) + 3 * S * sizeof(int) + (4 + 1 + 1) * S * sizeof(double);
+    return (12 + 6 + 12 + 3 + 6 + 7) * T1 * sizeof(double) + 3 * S * sizeof(int) + (4 + 1 + 1 + 1) * S * sizeof(double);
 }
 
 int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host, const double *robot_host)
@@ -470,7 +469,7 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
         return fail(h, MPCB_ESTATE, "step0 must continue the previous rollout (or be 0 to restart)");
     if (step1 <= step0 || step1 > h->pb.Nsim) return fail(h, MPCB_EINVAL, "step range out of bounds");
     if (!o->z || !o->u || !o->ee_pose || !o->ee_rpy || !o->ee_vel || !o->status || !o->sqp_iter || !o->qp_iter ||
-        !o->residuals || !o->cost || !o->solver_time || !o->errors)
+        !o->residuals || !o->cost || !o->solver_time || !o->errors || !o->plant_time)
         return fail(h, MPCB_EINVAL, "every result array must be provided");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -569,18 +568,18 @@ int mpcb_debug_workspace(mpcb_handle *h, int inst, double *out, size_t n_doubles
     return MPCB_OK;
 }
 
-int mpcb_summary(mpcb_handle *h, const mpcb_result *o, double plant_time_fraction, double *summary_dev, void *stream)
+int mpcb_summary(mpcb_handle *h, const mpcb_result *o, double *summary_dev, void *stream)
 {
     if (!h) return MPCB_EINVAL;
     if (!h->ready) return fail(h, MPCB_ESTATE, "mpcb_summary before mpcb_setup");
-    if (!o || !summary_dev || !o->errors || !o->status || !o->sqp_iter || !o->qp_iter || !o->residuals || !o->solver_time)
+    if (!o || !summary_dev || !o->errors || !o->status || !o->sqp_iter || !o->qp_iter || !o->residuals || !o->solver_time ||
+        !o->plant_time)
         return fail(h, MPCB_EINVAL, "mpcb_summary needs the errors, status, iteration, residual and time arrays");
-    if (!(plant_time_fraction >= 0.0 && plant_time_fraction <= 1.0)) return fail(h, MPCB_EINVAL, "plant_time_fraction outside [0,1]");
     HIPCHK(h, hipSetDevice(h->device));
     Outputs out;
     std::memcpy(&out, o, sizeof out);
     hipLaunchKernelGGL(mpc_summary_kernel, dim3((unsigned)h->pb.batch), dim3(WAVE), 0, (hipStream_t)stream, h->pb.batch, h->pb.Nsim,
-                       h->d_params, out, plant_time_fraction, summary_dev);
+                       h->d_params, out, summary_dev);
     HIPCHK(h, hipGetLastError());
     return MPCB_OK;
 }
@@ -626,7 +625,7 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
     if (rc) return rc;
     const size_t B = (size_t)p->batch, T1 = (size_t)p->Nsim + 1, S = (size_t)p->Nsim;
     const size_t nd[6] = {12 * T1, 6 * T1, 12 * T1, 3 * T1, 6 * T1, 7 * T1};
-    const size_t dbl_total = B * (nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + nd[5] + 6 * S);
+    const size_t dbl_total = B * (nd[0] + nd[1] + nd[2] + nd[3] + nd[4] + nd[5] + 7 * S);
     const size_t int_total = B * 3 * S;
     double *dd = nullptr;
     int *di = nullptr;
@@ -643,6 +642,7 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
     od.residuals = pd; pd += B * 4 * S;
     od.cost = pd; pd += B * S;
     od.solver_time = pd; pd += B * S;
+    od.plant_time = pd; pd += B * S;
     od.status = di; od.sqp_iter = di + B * S; od.qp_iter = di + 2 * B * S;
     rc = mpcb_rollout(h, 0, p->Nsim, &od, nullptr);
     if (rc == MPCB_OK) rc = mpcb_sync(h);
@@ -651,7 +651,7 @@ int mpcb_run(mpcb_handle *h, const mpcb_problem *p, const double *params_host, c
             {oh->z, od.z, B * nd[0] * 8}, {oh->u, od.u, B * nd[1] * 8}, {oh->ee_pose, od.ee_pose, B * nd[2] * 8},
             {oh->ee_rpy, od.ee_rpy, B * nd[3] * 8}, {oh->ee_vel, od.ee_vel, B * nd[4] * 8}, {oh->errors, od.errors, B * nd[5] * 8},
             {oh->residuals, od.residuals, B * 4 * S * 8}, {oh->cost, od.cost, B * S * 8},
-            {oh->solver_time, od.solver_time, B * S * 8}, {oh->status, od.status, B * S * 4},
+            {oh->solver_time, od.solver_time, B * S * 8}, {oh->plant_time, od.plant_time, B * S * 8}, {oh->status, od.status, B * S * 4},
             {oh->sqp_iter, od.sqp_iter, B * S * 4}, {oh->qp_iter, od.qp_iter, B * S * 4}};
         for (auto &c : cp) {
             if (!c.dst) continue;

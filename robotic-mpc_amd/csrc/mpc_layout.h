@@ -129,6 +129,7 @@ struct Outputs {
     double *cost;      // [batch][Nsim]
     double *solver_time; // [batch][Nsim] seconds (device realtime counter)
     double *errors;    // [batch][7][Nsim+1]  e1..e5, p_task_z, p_ee_y (simulator.py:265-344)
+    double *plant_time; // [batch][Nsim] seconds: plant step + FK / J qdot / error logging (simulator.py:224-226)
 };
 
 // One instance's workspace: five stage-major group arrays + persistent scalars.

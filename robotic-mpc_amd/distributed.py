@@ -67,80 +67,132 @@ def group_buckets(resolved: Sequence[Dict]) -> "OrderedDict[tuple, List[int]]":
     return buckets
 
 
-def _gather_to_root(local: Dict[str, np.ndarray], sizes: List[int]) -> Optional[Dict[str, np.ndarray]]:
-    """Gather per-rank arrays [n_r, ...] (n_r = sizes[r]) to rank 0; pads to max(sizes)."""
+def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[str, np.ndarray]]:
+    """The one exchange step of a sharded run: gather per-rank arrays [n_r, ...] (n_r = sizes[r]) to rank 0.
+
+    ``local`` holds torch tensors (device tensors from the engine) or numpy arrays.  With the ``nccl`` backend
+    (RCCL over xGMI) the DEVICE tensors go into ``dist.gather`` as they are -- no host hop before the collective --
+    and rank 0 copies the gathered tensors to the host once.  With ``gloo`` (CPU rehearsal) tensors are moved to
+    the host first.  The collective is chosen by the backend alone (``dist.gather`` exists for both), never per
+    rank or per exception: ranks that disagree on the collective would deadlock.  Shards are padded to
+    max(sizes) because gather needs equal shapes."""
     import torch
     import torch.distributed as dist
 
     ws, me = dist.get_world_size(), dist.get_rank()
-    backend = dist.get_backend()
-    dev = torch.device("cuda", local_device()) if backend == "nccl" else torch.device("cpu")
+    on_device = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_device()) if on_device else torch.device("cpu")
     nmax = max(sizes)
     out: Dict[str, np.ndarray] = {}
     for name in sorted(local):
         a = local[name]
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-        t = t.to(dev)
+        if t.device != dev:
+            t = t.to(dev)
         if t.shape[0] < nmax:
             pad = torch.zeros((nmax - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
             t = torch.cat([t, pad], dim=0)
         t = t.contiguous()
         bufs = [torch.empty_like(t) for _ in range(ws)] if me == 0 else None
-        try:
-            dist.gather(t, bufs, dst=0)
-        except (RuntimeError, NotImplementedError):  # backend without gather: fall back to all_gather
-            bufs_all = [torch.empty_like(t) for _ in range(ws)]
-            dist.all_gather(bufs_all, t)
-            bufs = bufs_all if me == 0 else None
+        dist.gather(t, bufs, dst=0)
         if me == 0:
-            out[name] = np.concatenate([b[: sizes[r]].cpu().numpy() for r, b in enumerate(bufs)], axis=0)
+            out[name] = np.concatenate([to_host(b[: sizes[r]]) for r, b in enumerate(bufs)], axis=0)
     return out if me == 0 else None
 
 
-def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Callable, use_dist: bool
-                    ) -> Optional[List[Dict[str, np.ndarray]]]:
+def to_host(v) -> np.ndarray:
+    """Device tensor -> numpy through a pinned staging buffer (one DMA at PCIe rate); numpy stays numpy."""
+    if isinstance(v, np.ndarray):
+        return v
+    if v.device.type == "cpu":
+        return v.numpy()
+    import torch
+
+    host = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+    host.copy_(v, non_blocking=False)
+    return host.numpy()
+
+
+def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Callable, use_dist: bool,
+                    info: Optional[Dict] = None) -> Optional[List[Dict[str, np.ndarray]]]:
     """Run all simulations bucket by bucket (sharded when ``use_dist``) and return one record per
-    simulation in queue order (rank 0; None on other ranks)."""
+    simulation in queue order (rank 0; None on other ranks).  ``info`` (optional dict) receives
+    ``kernel_ms`` (sum over the launches of this rank) and ``d2h_s`` (device -> host copy time)."""
+    import time
+
     ws, me = (world_size(), rank()) if use_dist else (1, 0)
     records: List[Optional[Dict[str, np.ndarray]]] = [None] * len(resolved)
     buckets = list(group_buckets(resolved).items())
-    # a runner with submit()/collect() launches every bucket before the first result is awaited
-    # (buckets smaller than the GPU then overlap); a plain callable runs them one after the other
-    tickets = {}
-    if hasattr(runner, "submit"):
-        for key, idxs in buckets:
+    kernel_ms, d2h_s = 0.0, 0.0
+    # a runner with submit()/collect() launches buckets before the first result is awaited (buckets smaller than
+    # the GPU then overlap); a plain callable runs them one after the other.  At most `max_in_flight` buckets hold
+    # an engine, a workspace and result buffers at any time.
+    max_in_flight = getattr(runner, "max_in_flight", 8)
+    tickets: Dict[tuple, object] = {}
+    pending = list(buckets)
+
+    def launch_more():
+        while pending and len(tickets) < max_in_flight and hasattr(runner, "submit"):
+            key, idxs = pending.pop(0)
             lo, hi = chunk_bounds(len(idxs), ws)[me]
             mine = [resolved[i] for i in idxs[lo:hi]]
             if mine:
                 tickets[key] = runner.submit(mine, chain_for(resolved[idxs[0]]))
+            else:
+                tickets[key] = None
+
+    launch_more()
     for key, idxs in buckets:
         bounds = chunk_bounds(len(idxs), ws)
         lo, hi = bounds[me]
         mine = [resolved[i] for i in idxs[lo:hi]]
-        chain = chain_for(resolved[idxs[0]])
         if key in tickets:
-            local = runner.collect(tickets.pop(key))
+            t = tickets.pop(key)
+            local = runner.collect(t) if t is not None else None
+            launch_more()
         else:
-            local = runner(mine, chain) if mine else None
+            local = runner(mine, chain_for(resolved[idxs[0]])) if mine else None
+        if local is not None and "_kernel_ms" in local:
+            kernel_ms += float(local.pop("_kernel_ms"))
+        t0 = time.perf_counter()
         if ws > 1:
             if local is None:  # this rank got no simulation of the bucket: contribute empty arrays
-                local = _empty_like_bucket(resolved[idxs[0]])
-            full = _gather_to_root({k: _np(v) for k, v in local.items()}, [b[1] - b[0] for b in bounds])
+                local = _empty_like_bucket(resolved[idxs[0]], with_summary=True)
+            elif "summary" not in local:
+                local = dict(local)
+                local["summary"] = _host_summary(local, mine)
+            full = gather_to_root(local, [b[1] - b[0] for b in bounds])
         else:
-            full = {k: _np(v) for k, v in local.items()}
+            full = {k: to_host(v) for k, v in local.items()}
+            if "summary" not in full:
+                full["summary"] = _host_summary(full, mine)
+        d2h_s += time.perf_counter() - t0
         if me == 0:
             for pos, qi in enumerate(idxs):
                 records[qi] = {k: v[pos] for k, v in full.items()}
+    if info is not None:
+        info["kernel_ms"] = kernel_ms
+        info["d2h_s"] = d2h_s
     return records if me == 0 else None  # type: ignore[return-value]
 
 
-def _np(v):
-    return v if isinstance(v, np.ndarray) else v.cpu().numpy()
+def _host_summary(local: Dict[str, object], cfgs: Sequence[Dict]) -> np.ndarray:
+    """Summary records for a runner that delivers only logs (the engine runner brings its own from the device)."""
+    from . import analysis
+
+    a = {k: to_host(v) for k, v in local.items()}
+    if len(cfgs) == 0:
+        return np.zeros((0, 24))
+    return analysis.batch_summary(a["errors"], a["sqp_iter"], a["qp_iter"], a["status"], a["residuals"], a["solver_time"],
+                                  a["plant_time"], np.array([c["dt"] for c in cfgs]), np.stack([c["w_task"] for c in cfgs]))
 
 
-def _empty_like_bucket(cfg: Dict) -> Dict[str, np.ndarray]:
-    from .engine import RESULT_FIELDS
+def _empty_like_bucket(cfg: Dict, with_summary: bool = False) -> Dict[str, np.ndarray]:
+    from .engine import NSUMMARY, RESULT_FIELDS
 
     S, T = cfg["Nsim"], cfg["Nsim"] + 1
-    return {name: np.zeros((0,) + shp(S, T), dtype=np.float64 if ty == "f8" else np.int32)
-            for name, ty, shp in RESULT_FIELDS}
+    out = {name: np.zeros((0,) + shp(S, T), dtype=np.float64 if ty == "f8" else np.int32)
+           for name, ty, shp in RESULT_FIELDS}
+    if with_summary:
+        out["summary"] = np.zeros((0, NSUMMARY))
+    return out

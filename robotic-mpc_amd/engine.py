@@ -30,7 +30,7 @@ RESULT_FIELDS = (
     ("ee_rpy", "f8", lambda S, T: (3, T)), ("ee_vel", "f8", lambda S, T: (6, T)),
     ("status", "i4", lambda S, T: (S,)), ("sqp_iter", "i4", lambda S, T: (S,)), ("qp_iter", "i4", lambda S, T: (S,)),
     ("residuals", "f8", lambda S, T: (S, 4)), ("cost", "f8", lambda S, T: (S,)), ("solver_time", "f8", lambda S, T: (S,)),
-    ("errors", "f8", lambda S, T: (7, T)),
+    ("errors", "f8", lambda S, T: (7, T)), ("plant_time", "f8", lambda S, T: (S,)),
 )
 ERROR_ROWS = ("e1", "e2", "e3", "e4", "e5", "p_task_z", "p_ee_y")   # rows of `errors` (simulator.py:337-344)
 NSUMMARY = 24
@@ -39,10 +39,6 @@ SUMMARY_COLS = ("rmse_e1", "rmse_e2", "rmse_e3", "rmse_e4", "rmse_e5", "itse_e1"
                 "weighted_rmse", "total_sqp_iterations", "avg_sqp_iterations", "num_failures", "max_kkt_residual",
                 "total_solver_time", "avg_mpc_time", "avg_solver_time", "avg_integration_time", "total_computation_time",
                 "total_qp_iterations")
-# share of a device-timed closed-loop step reported as the plant update (integration_time, simulator.py:224-226):
-# the plant step, FK / J qdot logging and the error column against the whole step, measured with the profile build
-# (profiles/r01_device_breakdown.txt: plant+log 6 of 800 us)
-PLANT_TIME_FRACTION = 0.0075
 
 
 class MpcbProblem(C.Structure):
@@ -53,7 +49,7 @@ class MpcbProblem(C.Structure):
 class MpcbResult(C.Structure):
     _fields_ = [("z", _dp), ("u", _dp), ("ee_pose", _dp), ("ee_rpy", _dp), ("ee_vel", _dp), ("status", _ip),
                 ("sqp_iter", _ip), ("qp_iter", _ip), ("residuals", _dp), ("cost", _dp), ("solver_time", _dp),
-                ("errors", _dp)]
+                ("errors", _dp), ("plant_time", _dp)]
 
 
 class EngineError(RuntimeError):
@@ -98,7 +94,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.mpcb_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.mpcb_kernel_info.argtypes = [C.c_void_p] + [_ip] * 4
     lib.mpcb_run.argtypes = [C.c_void_p, C.POINTER(MpcbProblem), _dp, _dp, C.POINTER(MpcbResult)]
-    lib.mpcb_summary.argtypes = [C.c_void_p, C.POINTER(MpcbResult), C.c_double, _dp, C.c_void_p]
+    lib.mpcb_summary.argtypes = [C.c_void_p, C.POINTER(MpcbResult), _dp, C.c_void_p]
     lib.mpcb_launch_info.argtypes = [C.c_void_p, _ip, _ip]
     if hasattr(lib, "mpcb_debug_task_lin"):
         lib.mpcb_debug_task_lin.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
@@ -210,8 +206,8 @@ class MpcBatchEngine:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         out = torch.empty((self._pb.batch, NSUMMARY), dtype=torch.float64, device=torch.device("cuda", self.device))
         r = self._result_struct(bufs)
-        self._check(self.lib.mpcb_summary(self._h, C.byref(r), C.c_double(PLANT_TIME_FRACTION),
-                                          C.cast(C.c_void_p(out.data_ptr()), _dp), C.c_void_p(stream)), "mpcb_summary")
+        self._check(self.lib.mpcb_summary(self._h, C.byref(r), C.cast(C.c_void_p(out.data_ptr()), _dp), C.c_void_p(stream)),
+                    "mpcb_summary")
         return out
 
     def debug_task_lin(self, cfgs: Sequence[Dict], chain, x: np.ndarray) -> np.ndarray:

@@ -6,8 +6,8 @@ simulator.py:668-674).  One ``.npz`` archive holds a whole run, batch-major:
     names            [K]  str          queue names (simulator.py:660)
     configs          [K]  str          the Simulator(**config) dict of each simulation as JSON
     keys             [K]  str          sha1 of (name, canonical config) -- the resume key
-    z [K,12,T1] u [K,6,T1] ee_pose [K,12,T1] ee_rpy [K,3,T1] ee_vel [K,6,T1]      (padded to the longest run)
-    status/sqp_iter/qp_iter [K,T] residuals [K,T,4] cost/solver_time [K,T]
+    z [K,12,T1] u [K,6,T1] ee_pose [K,12,T1] ee_rpy [K,3,T1] ee_vel [K,6,T1] errors [K,7,T1]   (padded to the longest run)
+    status/sqp_iter/qp_iter [K,T] residuals [K,T,4] cost/solver_time/plant_time [K,T]
     nsim             [K]  int          closed-loop steps of each simulation (its arrays use [:nsim(+1)])
 
 Everything is plain numpy (no pickle), so the archive is readable without this package.
@@ -21,9 +21,9 @@ from typing import Dict, List, Sequence
 
 import numpy as np
 
-LOG_KEYS_T1 = ("z", "u", "ee_pose", "ee_rpy", "ee_vel")            # [.., Nsim+1]
-LOG_KEYS_T = ("status", "sqp_iter", "qp_iter", "cost", "solver_time")  # [Nsim]
-FORMAT_VERSION = 1
+LOG_KEYS_T1 = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "errors")            # [.., Nsim+1]
+LOG_KEYS_T = ("status", "sqp_iter", "qp_iter", "cost", "solver_time", "plant_time")  # [Nsim]
+FORMAT_VERSION = 2
 
 
 def _jsonable(v):
@@ -51,7 +51,14 @@ def records_of(sim) -> Dict[str, np.ndarray]:
     sm = sim.simulation_model
     return {"z": sm.z, "u": sm.u, "ee_pose": sm._ee_pose_log, "ee_rpy": sm._ee_rpy_log, "ee_vel": sm._ee_velocity_log,
             "status": sim.solver_status, "sqp_iter": sim.sqp_iter, "qp_iter": sim.qp_iter, "residuals": sim.residuals,
-            "cost": sim.cost_history, "solver_time": sim.solver_time}
+            "cost": sim.cost_history, "solver_time": sim.solver_time, "plant_time": sim.integration_time,
+            "errors": analysis_rows(sim)}
+
+
+def analysis_rows(sim) -> np.ndarray:
+    from . import analysis
+
+    return analysis.errors_rows(sim.errors)
 
 
 def save_results(path: str, names: Sequence[str], configs: Sequence[Dict], records: Sequence[Dict[str, np.ndarray]]) -> str:

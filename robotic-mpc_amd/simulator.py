@@ -108,6 +108,8 @@ class Simulator:
                                    w_origin_task=w, w_normal_alignment_task=w, w_x_alignment_task=w,
                                    w_fixed_x_task=w, w_fixed_vy_task=w)
         self.scene = None  # MeshCat is out of scope (simulator.py:120-124 scene=False path)
+        self._errors_rows = None
+        self._summary_row = None
         self.mpc_time = np.zeros(self.Nsim)
         self.integration_time = np.zeros(self.Nsim)
         self.sqp_iter = np.zeros(self.Nsim, dtype=int)
@@ -130,20 +132,24 @@ class Simulator:
         return self
 
     def _attach(self, rec: Dict[str, np.ndarray]):
-        """Install one simulation's logs (arrays shaped like the reference's)."""
+        """Install one simulation's logs (arrays shaped like the reference's; views into the batch arrays of a
+        bucket are fine).  ``rec`` may carry ``errors`` [7, T1] (logged on the device with every column) and
+        ``summary`` [24] (mpcb_summary); what is missing is computed on demand from the logs."""
         self._invalidate_cache()
         self.simulation_model = _PlantLog(rec["z"], rec["u"], rec["ee_pose"], rec["ee_rpy"], rec["ee_vel"], self.dt)
-        self.sqp_iter = rec["sqp_iter"].astype(int)
-        self.qp_iter = rec["qp_iter"].astype(int)
-        self.solver_status = rec["status"].astype(int)
+        self.sqp_iter = rec["sqp_iter"]
+        self.qp_iter = rec["qp_iter"]
+        self.solver_status = rec["status"]
         self.residuals = rec["residuals"]
         self.solver_time = rec["solver_time"]
         self.cost_history = rec["cost"]
-        # simulator.py:214,226 time the Python calls around solve()/update(); here the whole step
-        # runs on the device: mpc_time is the device time of the step's solve, the plant update
-        # and logging are part of the same kernel and not timed separately.
-        self.mpc_time = rec["solver_time"].copy()
-        self.integration_time = np.zeros(self.Nsim)
+        # simulator.py:214,226 time the Python calls around solve() and update(); here both run on the device:
+        # mpc_time is the device time of the step's solve (there is no call overhead to add), integration_time
+        # the device time of the plant step with its FK / J qdot / error logging
+        self.mpc_time = rec["solver_time"]
+        self.integration_time = rec["plant_time"] if "plant_time" in rec else np.zeros(self.Nsim)
+        self._errors_rows = rec.get("errors")
+        self._summary_row = rec.get("summary")
         self._data_computed = True
 
     def _invalidate_cache(self):
@@ -159,6 +165,8 @@ class Simulator:
     @cached_property
     def errors(self):
         self._need_run("errors")
+        if getattr(self, "_errors_rows", None) is not None:
+            return analysis.errors_dict(self._errors_rows)
         sm = self.simulation_model
         return analysis.compute_errors(sm._ee_pose_log, sm._ee_velocity_log, self.resolved["coeffs"], self.translation,
                                        self.px_ref, self.vy_ref)
@@ -166,6 +174,11 @@ class Simulator:
     @cached_property
     def metrics(self):
         self._need_run("metrics")
+        r = getattr(self, "_summary_row", None)
+        if r is not None:   # reduced with the batch (mpcb_summary / analysis.batch_summary)
+            keys = ("e1", "e2", "e3", "e4", "e5")
+            return {"weighted_rmse": float(r[10]), "rmse": {k: float(r[i]) for i, k in enumerate(keys)},
+                    "itse": {k: float(r[5 + i]) for i, k in enumerate(keys)}}
         return analysis.compute_metrics(self.errors, self.dt)
 
     @cached_property
@@ -192,6 +205,14 @@ class Simulator:
     def get_summary(self):
         """simulator.py:509-547."""
         self._need_run("summary")
+        r = getattr(self, "_summary_row", None)
+        if r is not None:
+            from .engine import SUMMARY_COLS
+
+            out = {k: float(r[i]) for i, k in enumerate(SUMMARY_COLS[:20])}
+            for k in ("total_sqp_iterations", "num_failures"):
+                out[k] = int(round(out[k]))
+            return out
         m, s, t = self.metrics, self.solver_stats, self.timings
         return {
             "rmse_e1": m["rmse"]["e1"], "rmse_e2": m["rmse"]["e2"], "rmse_e3": m["rmse"]["e3"],
@@ -207,14 +228,55 @@ class Simulator:
         }
 
 
+class _ResultItem(dict):
+    """One entry of run_all's list: {'name','simulator','data','analysis','summary'} (simulator.py:668-674).
+    'data' and 'analysis' are dicts of arrays derived from the logs; they are built on first access, so a grid
+    search of thousands of simulations hands its results back without a per-simulation numpy pass."""
+
+    _LAZY = {"data": "get_data", "analysis": "get_analysis", "summary": "get_summary"}
+
+    def __init__(self, name, sim):
+        super().__init__(name=name, simulator=sim)
+
+    def __missing__(self, key):
+        if key in self._LAZY:
+            v = getattr(dict.__getitem__(self, "simulator"), self._LAZY[key])()
+            dict.__setitem__(self, key, v)
+            return v
+        raise KeyError(key)
+
+    def _fill(self):
+        for k in self._LAZY:
+            self[k]
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return key in self._LAZY or dict.__contains__(self, key)
+
+    def keys(self): self._fill(); return dict.keys(self)
+    def items(self): self._fill(); return dict.items(self)
+    def values(self): self._fill(); return dict.values(self)
+    def __iter__(self): self._fill(); return dict.__iter__(self)
+    def __len__(self): return 5
+
+
 # a runner maps (list of resolved configs of one bucket, chain) -> dict of arrays [batch, ...]
 Runner = Callable[[Sequence[Dict], robots.KinematicChain], Dict[str, np.ndarray]]
 
 
 class _EngineRunner:
     """Default runner: the HIP engine.  Callable (one bucket, synchronous) and, for queues with several
-    buckets, submit()/collect(): every bucket gets its own engine handle and HIP stream, so the
-    launches of small buckets (fewer simulations than CUs) overlap on the GPU."""
+    buckets, submit()/collect(): every bucket in flight has its own engine handle and HIP stream, so the
+    launches of small buckets (fewer simulations than CUs) overlap on the GPU.  collect() returns DEVICE
+    tensors (the logs and the per-simulation summary reduced on the device by mpcb_summary): the caller
+    gathers them across ranks (RCCL) or copies them to the host, once."""
+
+    max_in_flight = 8   # buckets holding an engine + workspace + result buffers at the same time
 
     def __init__(self, device: int):
         self.device = device
@@ -237,12 +299,15 @@ class _EngineRunner:
         with torch.cuda.stream(stream):
             bufs = eng.alloc_results(pb)
             eng.rollout(bufs, 0, pb.Nsim, stream=stream.cuda_stream)
-        return eng, stream, bufs
+            summary = eng.summary(bufs, stream=stream.cuda_stream)
+        return eng, stream, bufs, summary
 
     def collect(self, ticket):
-        eng, stream, bufs = ticket
+        eng, stream, bufs, summary = ticket
         stream.synchronize()
-        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        out = dict(bufs)
+        out["summary"] = summary
+        out["_kernel_ms"] = eng.kernel_ms()
         self._idle.append(eng)
         return out
 
@@ -365,8 +430,12 @@ class SimulationManager:
                 if j is not None:
                     done[i] = results_io.record_at(arch, j)
         todo = [i for i in range(len(sims)) if i not in done]
-        new = dmod.run_partitioned([resolved[i] for i in todo], runner, chain_for, use_dist) if todo else []
-        self.last_run_info = {"n_sims": len(sims), "n_resumed": len(done), "wall_s": time.time() - t_start,
+        info: Dict[str, Any] = {}
+        t_run = time.time()
+        new = dmod.run_partitioned([resolved[i] for i in todo], runner, chain_for, use_dist, info) if todo else []
+        self.last_run_info = {"n_sims": len(sims), "n_resumed": len(done), "setup_s": t_run - t_start,
+                              "run_s": time.time() - t_run, "kernel_ms": info.get("kernel_ms", 0.0),
+                              "d2h_s": info.get("d2h_s", 0.0),
                               "buckets": len({packing.bucket_key(resolved[i]) for i in todo}),
                               "world_size": dmod.world_size() if use_dist else 1}
         if new is None or (use_dist and dmod.rank() != 0):  # non-root rank
@@ -391,6 +460,6 @@ class SimulationManager:
         for sim, rec in zip(sims, records):
             sim._attach(rec)
             if return_results:
-                results.append({"name": sim.name, "simulator": sim, "data": sim.get_data(),
-                                "analysis": sim.get_analysis(), "summary": sim.get_summary()})
+                results.append(_ResultItem(sim.name, sim))
+        self.last_run_info["wall_s"] = time.time() - t_start
         return results if return_results else None

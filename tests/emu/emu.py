@@ -36,14 +36,14 @@ def run(cfgs, chain, step_chunk=0, pool_doubles=0, waves=1):
     o = dict(z=np.zeros((B, 12, T1)), u=np.zeros((B, 6, T1)), ee_pose=np.zeros((B, 12, T1)), ee_rpy=np.zeros((B, 3, T1)),
              ee_vel=np.zeros((B, 6, T1)), status=np.zeros((B, Nsim), np.int32), sqp_iter=np.zeros((B, Nsim), np.int32),
              qp_iter=np.zeros((B, Nsim), np.int32), residuals=np.zeros((B, Nsim, 4)), cost=np.zeros((B, Nsim)),
-             solver_time=np.zeros((B, Nsim)), errors=np.zeros((B, 7, T1)))
+             solver_time=np.zeros((B, Nsim)), errors=np.zeros((B, 7, T1)), plant_time=np.zeros((B, Nsim)))
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     args = [C.byref(pb), robot.ctypes.data_as(dp), params.ctypes.data_as(dp)]
     for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
         args.append(o[k].ctypes.data_as(dp))
     for k in ("status", "sqp_iter", "qp_iter"):
         args.append(o[k].ctypes.data_as(ip))
-    for k in ("residuals", "cost", "solver_time", "errors"):
+    for k in ("residuals", "cost", "solver_time", "errors", "plant_time"):
         args.append(o[k].ctypes.data_as(dp))
     args.append(C.c_int(step_chunk))
     args.append(C.c_int(pool_doubles))

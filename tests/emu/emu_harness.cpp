@@ -114,10 +114,10 @@ static int emu_run_t(const Problem *pb, const double *robot105, const double *pa
 
 extern "C" int emu_run(const Problem *pb, const double *robot105, const double *params /* [batch][MPCB_NPARAM] */,
                        double *z, double *u, double *ee_pose, double *ee_rpy, double *ee_vel, int *status,
-                       int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time, double *errors,
+                       int *sqp_iter, int *qp_iter, double *residuals, double *cost, double *solver_time, double *errors, double *plant_time,
                        int step_chunk, int pool_doubles, int waves)
 {
-    Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time, errors};
+    Outputs out{z, u, ee_pose, ee_rpy, ee_vel, status, sqp_iter, qp_iter, residuals, cost, solver_time, errors, plant_time};
     if (waves == 8) return emu_run_t<8>(pb, robot105, params, out, step_chunk, pool_doubles);
     if (waves == 4) return emu_run_t<4>(pb, robot105, params, out, step_chunk, pool_doubles);
     if (waves == 2) return emu_run_t<2>(pb, robot105, params, out, step_chunk, pool_doubles);

@@ -149,8 +149,9 @@ def oracle_runner(cfgs, chain):
     for r, c in zip(recs, cfgs):   # the engine logs the task errors with every column; here they come from the numpy analysis
         e = analysis.compute_errors(r["ee_pose"], r["ee_vel"], c["coeffs"], c["t_ee"], c["px_ref"], c["vy_ref"])
         r["errors"] = np.stack([e[k] for k in ("e1", "e2", "e3", "e4", "e5", "p_task_z", "p_ee_y")])
+        r["plant_time"] = np.zeros_like(r["solver_time"])
     keys = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "status", "sqp_iter", "qp_iter", "residuals", "cost", "solver_time",
-            "errors")
+            "errors", "plant_time")
     return {k: np.stack([r[k] for r in recs]) for k in keys}
 
 

@@ -36,7 +36,7 @@ def test_version_and_sizes(lib):
     ws = lib.mpcb_workspace_bytes(C.byref(pb))
     assert 256 * 101 * 600 * 8 < ws < 256 * 101 * 1200 * 8  # a few hundred doubles per stage
     per_sim = lib.mpcb_result_bytes_per_sim(C.byref(pb))
-    assert per_sim == (46 * 601 + 6 * 600) * 8 + 3 * 600 * 4
+    assert per_sim == (46 * 601 + 7 * 600) * 8 + 3 * 600 * 4
     assert packing.NPARAM == 72
     bad = engine.MpcbProblem(0, 100, 600, 1, 100, 50, 0, 0)
     assert lib.mpcb_workspace_bytes(C.byref(bad)) == 0
@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     from robotic_mpc_amd import engine
 
     assert C.sizeof(engine.MpcbProblem) == 32
-    assert C.sizeof(engine.MpcbResult) == 12 * 8
+    assert C.sizeof(engine.MpcbResult) == 13 * 8
 
 
 @pytest.mark.skipif(__import__("conftest").has_gpu(), reason="checks the no-device behaviour")
