@@ -46,6 +46,18 @@ extern "C" {
 #define MPCB_SOLVER_SQP 0     /* trajectory_optimizer.py:60 (default) */
 #define MPCB_SOLVER_SQP_RTI 1 /* solver_options {'nlp_solver_type': 'SQP_RTI'} */
 
+#define MPCB_PRECISION_FP64 0          /* everything in fp64 (the reference's arithmetic)                      */
+#define MPCB_PRECISION_FP32_RICCATI 1  /* Riccati factor K, P, R~^-1, p and the three solve sweeps in fp32; iterate,
+                                          residuals, right-hand sides, steps and all outputs stay fp64
+                                          (BASELINE.json configs[4]; SQP_RTI on the throughput engine only)     */
+
+/* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 2-4
+ * wavefronts and most of a CU's LDS per simulation; batches up to a few simulations per CU, and every SQP run) and
+ * the THROUGHPUT engine (one wavefront per simulation, records streamed; SQP_RTI batches of >= MPCB_STREAM_MIN_BATCH
+ * simulations, and every fp32-Riccati run).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
+ * overrides the choice where both apply. */
+#define MPCB_STREAM_MIN_BATCH 2048
+
 typedef struct mpcb_handle mpcb_handle;
 
 /* Batch-uniform part of the configuration (one launch = one bucket of simulations that
@@ -58,7 +70,7 @@ typedef struct {
     int max_iter;     /* nlp_solver_max_iter (trajectory_optimizer.py:67)                 */
     int qp_iter_max;  /* acados qp_solver_iter_max (default 50)                           */
     int fixed_step;   /* 1: globalization FIXED_STEP, 0: MERIT_BACKTRACKING (:68)         */
-    int reserved;
+    int precision;    /* MPCB_PRECISION_*: arithmetic of the Riccati factor and solve sweeps */
 } mpcb_problem;
 
 /* Per-simulation parameter record, MPCB_NPARAM doubles (simulator.py:18-35):
@@ -134,6 +146,9 @@ int mpcb_last_kernel_ms(mpcb_handle *h, float *ms);
 
 /* Static resources of the rollout kernel: VGPRs, SGPRs(0 if unknown), LDS bytes, scratch bytes. */
 int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
+
+/* Kernel family mpcb_setup chose for the current problem: 0 latency engine, 1 throughput engine (< 0: error). */
+int mpcb_engine(mpcb_handle *h);
 
 /* Launch geometry chosen by mpcb_setup for the current batch: wavefronts cooperating on one
  * simulation (one workgroup per simulation), and the dynamic-LDS chunk pool per workgroup. */

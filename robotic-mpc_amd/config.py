@@ -28,7 +28,10 @@ OPTIONAL_DEFAULTS = {
 EXTENSION_DEFAULTS = {"translation_ee_t": (0.0, 0.0, 0.1), "urdf_path": None, "ee_frame": None,
                       # plant integrator of simulation_model.Robot (simulation_model.py:13,39-51); the reference's
                       # Simulator hard-codes "RK4" (simulator.py:85)
-                      "integration_method": "RK4"}
+                      "integration_method": "RK4",
+                      # arithmetic of the Riccati factor / solve sweeps: "fp64" (the reference's) or "fp32"
+                      # (BASELINE configs[4]; SQP_RTI only)
+                      "riccati_precision": "fp64"}
 # codes of the parameter record (include/mpcbatch.h [7]); RK4 = 0 keeps default records unchanged
 PLANT_INTEGRATORS = {"RK4": 0, "Euler": 1, "RK2": 2, "RK3": 3}
 
@@ -193,6 +196,10 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
         raise ValueError("wcv must be positive (prediction_model.py:94 divides by it)")
     if cfg["integration_method"] not in PLANT_INTEGRATORS:
         raise ValueError(f"Unknown integration method: {cfg['integration_method']}")  # simulation_model.py:51
+    if cfg["riccati_precision"] not in ("fp64", "fp32"):
+        raise ValueError("riccati_precision must be 'fp64' or 'fp32'")
+    if cfg["riccati_precision"] == "fp32" and so["nlp_solver_type"] != "SQP_RTI":
+        raise ValueError("riccati_precision='fp32' is implemented for nlp_solver_type='SQP_RTI' only")
     t_ee = np.asarray(cfg["translation_ee_t"], dtype=np.float64).reshape(-1)
     if t_ee.shape != (3,):
         raise ValueError("translation_ee_t must have 3 entries")
@@ -205,6 +212,7 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
         "tol": so["nlp_solver_tol_stat"], "tol_eq": so["nlp_solver_tol_eq"], "tol_ineq": so["nlp_solver_tol_ineq"],
         "tol_comp": so["nlp_solver_tol_comp"], "qp_tol": so["qp_tol"], "levenberg_marquardt": so["levenberg_marquardt"],
         "fixed_step": so["globalization"] == "FIXED_STEP",
+        "precision": 1 if cfg["riccati_precision"] == "fp32" else 0,
         "wcv": wcv, "q0": _vec6(cfg, "q_0"), "qdot0": _vec6(cfg, "qdot_0"),
         "qmin": _vec6(cfg, "q_min"), "qmax": _vec6(cfg, "q_max"),
         "umin": _vec6(cfg, "qdot_min"), "umax": _vec6(cfg, "qdot_max"),

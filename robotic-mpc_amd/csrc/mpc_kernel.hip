@@ -18,6 +18,7 @@
 #include "../../include/mpcbatch.h"
 #include "mpc_core.h"
 #include "mpc_pack.h"
+#include "mpc_stream.h"
 
 using namespace mpcb;
 
@@ -36,7 +37,9 @@ extern __shared__ __attribute__((aligned(16))) double g_pool[];
 #define MPCB_POLL_SLEEP 2
 #endif
 
-template <int NWV>
+// WPE (wavefronts per SIMD the kernel is compiled for) only makes the executor -- and with it every pass of the
+// engine template -- a distinct type per kernel variant, so each variant gets its own register allocation.
+template <int NWV, int WPE = 1>
 struct DevExec {
     static constexpr int NT = WAVE * NWV;
     __device__ __forceinline__ static int lane_id() { return (int)threadIdx.x; }
@@ -212,21 +215,37 @@ struct DevExec {
     __device__ __forceinline__ double clock() { return (double)wall_clock64() * 1e-8; }
 };
 
-#ifndef MPCB_WPE
-#define MPCB_WPE 1
-#endif
-template <int NWV>
-__global__ __launch_bounds__(WAVE *NWV, MPCB_WPE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+// WPE = 1: one wavefront per SIMD owns the whole 512-entry register file (one simulation per CU: batch <= #CUs, and
+// the 1 / 2 / 8-wavefront geometries).  WPE = 2: 256 registers, two 4-wavefront simulations resident per CU -- the
+// geometry of batches beyond one simulation per CU (measured at batch 4096, N = 100: 540 k steps/s against 468 k for
+// two 2-wavefront simulations per CU at 512 registers).
+template <int NWV, int WPE = 1>
+__global__ __launch_bounds__(WAVE *NWV, WPE) void mpc_rollout_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
                                                            double *ws_base, size_t ws_stride, Outputs out, int step0,
                                                            int step1, int pool_doubles)
 {
     const int inst = blockIdx.x;
     if (inst >= pb.batch) return;
-    DevExec<NWV> ex;
+    DevExec<NWV, WPE> ex;
     load_constants(ex, params + inst, &rb);
     Ctx c{&pb, ws_carve(ws_base + (size_t)inst * ws_stride, pb.N), pool_doubles, pb.N};
-    Engine<DevExec<NWV>> eng(ex, c);
+    Engine<DevExec<NWV, WPE>> eng(ex, c);
     eng.rollout(out, inst, step0, step1);
+}
+
+// THROUGHPUT engine (mpc_stream.h): one wavefront = one workgroup = one simulation, MPCB_STREAM_WPE wavefronts per SIMD.
+#ifndef MPCB_STREAM_WPE
+#define MPCB_STREAM_WPE 2
+#endif
+template <class FT>
+__global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+                                                                           double *ws_base, size_t ws_stride, Outputs out, int step0, int step1)
+{
+    const int inst = blockIdx.x;
+    if (inst >= pb.batch) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    se::rollout<FT>(pb, params, &rb, ws_base, ws_stride, out, inst, step0, step1);
+#endif
 }
 
 // Per-simulation summary of Simulator.get_summary (simulator.py:509-547) from the device logs: one wavefront per
@@ -309,6 +328,8 @@ struct mpcb_handle {
     int pool_doubles = POOL_DEFAULT_DOUBLES;
     int num_cus = 256;
     int waves_per_sim = 4;
+    int wpe = 1;               // latency engine: kernel variant compiled for this many wavefronts per SIMD
+    int engine = 0;            // 0: latency engine (mpc_core.h), 1: throughput engine (mpc_stream.h)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -337,6 +358,10 @@ static int check_problem(mpcb_handle *h, const mpcb_problem *p)
     if (p->solver_type != MPCB_SOLVER_SQP && p->solver_type != MPCB_SOLVER_SQP_RTI)
         return fail(h, MPCB_EINVAL, "solver_type must be MPCB_SOLVER_SQP or MPCB_SOLVER_SQP_RTI");
     if (p->max_iter < 1 || p->qp_iter_max < 1) return fail(h, MPCB_EINVAL, "iteration limits must be >= 1");
+    if (p->precision != MPCB_PRECISION_FP64 && p->precision != MPCB_PRECISION_FP32_RICCATI)
+        return fail(h, MPCB_EINVAL, "precision must be MPCB_PRECISION_FP64 or MPCB_PRECISION_FP32_RICCATI");
+    if (p->precision == MPCB_PRECISION_FP32_RICCATI && p->solver_type != MPCB_SOLVER_SQP_RTI)
+        return fail(h, MPCB_EINVAL, "the fp32 Riccati leg runs on the throughput engine, which implements SQP_RTI only");
     return MPCB_OK;
 }
 
@@ -387,10 +412,28 @@ void mpcb_destroy(mpcb_handle *h)
 
 const char *mpcb_last_error(const mpcb_handle *h) { return h ? h->err.c_str() : "invalid handle"; }
 
+// which kernel family runs `p` (see include/mpcbatch.h)
+static int pick_engine(const mpcb_problem *p)
+{
+    if (p->solver_type != MPCB_SOLVER_SQP_RTI) return 0;
+    if (p->precision == MPCB_PRECISION_FP32_RICCATI) return 1;
+    int e = p->batch >= MPCB_STREAM_MIN_BATCH ? 1 : 0;
+    if (const char *env = getenv("MPCB_ENGINE")) {
+        if (!strcmp(env, "stream")) e = 1;
+        else if (!strcmp(env, "latency")) e = 0;
+    }
+    return e;
+}
+static size_t ws_doubles_for(const mpcb_problem *p)
+{
+    if (pick_engine(p) == 0) return ws_doubles_per_instance(p->N);
+    return p->precision == MPCB_PRECISION_FP32_RICCATI ? se::sws_doubles_per_instance<float>(p->N) : se::sws_doubles_per_instance<double>(p->N);
+}
+
 size_t mpcb_workspace_bytes(const mpcb_problem *p)
 {
     if (!p || p->N < 1 || p->batch < 1) return 0;
-    return (size_t)p->batch * ws_doubles_per_instance(p->N) * sizeof(double);
+    return (size_t)p->batch * ws_doubles_for(p) * sizeof(double);
 }
 
 size_t mpcb_result_bytes_per_sim(const mpcb_problem *p)
@@ -427,7 +470,8 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         h->params_cap = pbytes;
     }
     HIPCHK(h, hipMemcpy(h->d_params, packed.data(), pbytes, hipMemcpyHostToDevice));
-    h->ws_stride = ws_doubles_per_instance(p->N);
+    h->engine = pick_engine(p);
+    h->ws_stride = ws_doubles_for(p);
     const size_t wbytes = mpcb_workspace_bytes(p);
     if (wbytes > h->ws_cap) {
         if (h->d_ws) (void)hipFree(h->d_ws);
@@ -450,9 +494,14 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         h->pool_doubles = (bytes / 16) * 2;
         // wavefronts per simulation: the four SIMDs of a CU are otherwise idle at one simulation per CU
         const char *env = getenv("MPCB_WAVES_PER_SIM");
-        int nw = wpc <= 1 ? 4 : (wpc <= 2 ? 2 : 1);
-        if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) nw = atoi(env);
+        // one simulation per CU: 4 wavefronts, 512 registers; beyond: two 4-wavefront simulations per CU at 256 registers
+        int nw = wpc <= 2 ? 4 : 1;
+        int wpe = wpc == 2 ? 2 : 1;
+        if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }
+        if (const char *e3 = getenv("MPCB_WPE")) { if (atoi(e3) == 2 && nw == 4) wpe = 2; else if (atoi(e3) == 1) wpe = 1; }
         h->waves_per_sim = nw;
+        h->wpe = wpe;
+        if (h->engine == 1) { h->waves_per_sim = 1; h->pool_doubles = 0; }   // throughput engine: one wavefront, static LDS only
     }
     h->ready = true;
     h->next_step = 0;
@@ -475,13 +524,29 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     hipStream_t s = (hipStream_t)stream;
     Outputs out;
     std::memcpy(&out, o, sizeof out);
+    if (h->engine == 1) {
+        HIPCHK(h, hipEventRecord(h->ev0, s));
+        const dim3 sgrid((unsigned)h->pb.batch);
+        if (h->pb.precision == MPCB_PRECISION_FP32_RICCATI)
+            hipLaunchKernelGGL(mpc_stream_kernel<float>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
+                               step0, step1);
+        else
+            hipLaunchKernelGGL(mpc_stream_kernel<double>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
+                               step0, step1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, s));
+        h->last_stream = s;
+        h->timed = true;
+        h->next_step = step1;
+        return MPCB_OK;
+    }
     const size_t lds = (size_t)h->pool_doubles * sizeof(double);
     {
         // the dynamic-LDS ceiling is a process-wide attribute of the kernel, not of this handle: always raise it to
         // the largest pool any handle can ask for, right before the launch
         static const int max_lds = (160 * 1024 - (int)sizeof(Smem) - 64) / 16 * 16;
         const void *fn = h->waves_per_sim == 8 ? (const void *)mpc_rollout_kernel<8>
-                       : h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
+                       : h->waves_per_sim == 4 ? (h->wpe == 2 ? (const void *)mpc_rollout_kernel<4, 2> : (const void *)mpc_rollout_kernel<4>)
                        : h->waves_per_sim == 2 ? (const void *)mpc_rollout_kernel<2> : (const void *)mpc_rollout_kernel<1>;
         HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
@@ -489,6 +554,9 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     const dim3 grid((unsigned)h->pb.batch);
     if (h->waves_per_sim == 8)
         hipLaunchKernelGGL(mpc_rollout_kernel<8>, grid, dim3(WAVE * 8), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
+                           h->ws_stride, out, step0, step1, h->pool_doubles);
+    else if (h->waves_per_sim == 4 && h->wpe == 2)
+        hipLaunchKernelGGL((mpc_rollout_kernel<4, 2>), grid, dim3(WAVE * 4), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
                            h->ws_stride, out, step0, step1, h->pool_doubles);
     else if (h->waves_per_sim == 4)
         hipLaunchKernelGGL(mpc_rollout_kernel<4>, grid, dim3(WAVE * 4), lds, s, h->pb, h->rb, h->d_params, h->d_ws,
@@ -528,8 +596,12 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
 {
     if (!h) return MPCB_EINVAL;
     hipFuncAttributes a;
+    if (h->engine == 1) {
+        HIPCHK(h, hipFuncGetAttributes(&a, h->pb.precision == MPCB_PRECISION_FP32_RICCATI ? (const void *)mpc_stream_kernel<float>
+                                                                                          : (const void *)mpc_stream_kernel<double>));
+    } else
     HIPCHK(h, hipFuncGetAttributes(&a, h->waves_per_sim == 8 ? (const void *)mpc_rollout_kernel<8>
-                                       : h->waves_per_sim == 4 ? (const void *)mpc_rollout_kernel<4>
+                                       : h->waves_per_sim == 4 ? (h->wpe == 2 ? (const void *)mpc_rollout_kernel<4, 2> : (const void *)mpc_rollout_kernel<4>)
                                        : h->waves_per_sim == 2 ? (const void *)mpc_rollout_kernel<2>
                                                                : (const void *)mpc_rollout_kernel<1>));
     if (vgprs) *vgprs = a.numRegs;
@@ -537,6 +609,12 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
     if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
     if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
     return MPCB_OK;
+}
+
+int mpcb_engine(mpcb_handle *h)
+{
+    if (!h || !h->ready) return MPCB_EINVAL;
+    return h->engine;
 }
 
 int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes)
@@ -553,7 +631,7 @@ int mpcb_debug_profile(mpcb_handle *h, int inst, double *out16)
 {
     if (!h || !out16 || !h->ready || inst < 0 || inst >= h->pb.batch) return MPCB_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    const double *src = h->d_ws + (size_t)inst * h->ws_stride + (size_t)(h->pb.N + 1) * STAGE_DOUBLES + 32;
+    const double *src = h->d_ws + (size_t)inst * h->ws_stride + (h->ws_stride - STATE_DOUBLES) + 32;
     HIPCHK(h, hipMemcpy(out16, src, NPROF * sizeof(double), hipMemcpyDeviceToHost));
     return MPCB_OK;
 }

@@ -111,7 +111,7 @@ struct Problem {
     int max_iter;     // nlp_solver_max_iter
     int qp_iter_max;  // HPIPM iter_max
     int fixed_step;   // globalization FIXED_STEP instead of MERIT_BACKTRACKING
-    int pad;
+    int precision;    // 0: fp64 everywhere; 1: Riccati factor and solve sweeps in fp32 (throughput engine only)
 };
 
 // Device pointers to the result logs (== mpcb_result), batch-major, per-instance shapes of

@@ -1,0 +1,1233 @@
+// mpc_stream.h -- the THROUGHPUT engine of the batched MPC rollout (gfx950): one wavefront = one simulation,
+// several wavefronts per SIMD, stage records STREAMED through a few KB of LDS.
+//
+// mpc_core.h is the latency engine: one workgroup of 2-4 wavefronts and (almost) a whole CU's LDS per simulation,
+// big chunks of the horizon staged in LDS, the sequential Riccati recursion of ONE wavefront as the critical path.
+// That design idles a CU's issue slots once there are many more simulations than CUs (batch >= ~1000 per GPU:
+// BASELINE configs[2], [3]).  Here the roles are collapsed into one wavefront per simulation:
+//   * every pass of the interior-point iteration is a loop over the stages; the records of the next stage of the
+//     sweep are fetched -- 16 B per lane, one to three instructions per record bundle -- while the current stage is
+//     computed, and the results of a stage leave as soon as they exist.  No chunk pool, no halo rows, no
+//     `s_barrier` (a wavefront's LDS operations complete in issue order);
+//   * what hides the memory and LDS latency is not a second wavefront of the same simulation but the OTHER
+//     simulations resident on the same SIMD (2 at 256 VGPRs), each with < 20 KB of LDS;
+//   * in every stage the lanes of the wavefront take different roles at once (matrix recursion | vector recursion;
+//     state recursion | input step | multiplier step | step-length terms of the stage before).
+// Record groups G1..G3 in HBM are those of mpc_layout.h; the factor record G4 has its fields padded to multiples
+// of four scalars (S* offsets below) so that every bundle is a whole number of 16-byte items in fp64 AND fp32.
+//
+// The Riccati factor and the three solve sweeps are templated on a scalar type FT: FT = double is the reference
+// arithmetic; FT = float is the "fp32 Riccati" leg of BASELINE configs[4] (factor K, P, R~^-1, p and the sweep
+// recursions in fp32 -- half the bytes of the largest record; iterate, residuals, right-hand sides, step lengths,
+// multiplier steps and all logged outputs stay fp64).
+//
+// Algorithm and formulas: those of mpc_core.h (acados SQP_RTI + HPIPM Mehrotra IPM + Riccati, restated from
+// trajectory_optimizer.py:57-176 and simulator.py:199-241); see there for derivations.  Only SQP_RTI runs on this
+// engine (full SQP with its line search keeps the latency engine).
+#pragma once
+#include "mpc_core.h"
+
+namespace mpcb {
+namespace se {
+
+typedef double D2 __attribute__((ext_vector_type(2)));
+
+// factor record of one stage, in scalars of type FT (fields padded to multiples of 4 scalars)
+constexpr int SK = 0;      // K = R~^-1 S~ (6x12)
+constexpr int SVH = 72;    // R~^-1 h_u (6) + 2 pad
+constexpr int SEo = 80;    // e = rb - B R~^-1 h_u (12)
+constexpr int SPV = 92;    // p_k (12)
+constexpr int SPM = 104;   // P_k packed upper triangle (78) + 2 pad
+constexpr int SWV = 184;   // w_k = P_{k+1} rb_k (12)
+constexpr int SRI = 196;   // R~^-1 (36)
+constexpr int SW4 = 232;
+constexpr int SW4_AFF = SPV, SW4_FWD = SWV;
+
+struct SWs {
+    double *G1, *G2, *G3;
+    char *G4;          // rows of SW4 scalars of the factor type
+    double *state;
+};
+template <class FT>
+MPC_HD size_t sws_doubles_per_instance(int N)
+{
+    return (size_t)(N + 1) * (W1 + W2 + W3 + SW4 * sizeof(FT) / 8) + STATE_DOUBLES;
+}
+template <class FT>
+MPC_HD SWs sws_carve(double *base, int N)
+{
+    const size_t n1 = (size_t)N + 1;
+    SWs w;
+    double *p = base;
+    w.G1 = p; p += n1 * W1;
+    w.G2 = p; p += n1 * W2;
+    w.G3 = p; p += n1 * W3;
+    w.G4 = (char *)p; p += n1 * (SW4 * sizeof(FT) / 8);
+    w.state = p;
+    return w;
+}
+
+// --------------------------------------------------------------------------------------------- LDS of one simulation
+constexpr int OUT_MAX = 232;   // doubles of the largest output bundle (factor record)
+// Input ring: a flat LDS area cut into as many slots as fit the pass's bundle (rounded up to whole 1-KiB copy pieces:
+// one global_load_lds_dwordx4 writes 64 x 16 B contiguously).  Slot = row % slots; rows k-1, k, k+1 of the sweep are
+// valid while stage k is computed, the slots beyond hold rows in flight.
+#ifndef MPCB_RING_DOUBLES
+#define MPCB_RING_DOUBLES 1280
+#endif
+constexpr int RING_DOUBLES = MPCB_RING_DOUBLES;
+constexpr int SLOGB = 4;       // log columns collected before they leave (LOGB of the latency engine is 8: LDS is scarcer here)
+
+struct SSmem {
+    InstParams P;
+    alignas(16) Robot rb;
+    SWs w;
+    int n_hor, pad0;
+    alignas(16) double ring[RING_DOUBLES];
+    alignas(16) double out[2][OUT_MAX];
+    alignas(16) double Rt[36];        // R~ of the stage in work
+    alignas(16) double St2[2][72];    // S~ (stage k read, k-1 written)
+    alignas(16) double Kf[72];        // K of the stage in work
+    alignas(16) double vec[4][16];    // 12-vectors handed from phase to phase / stage to stage
+    alignas(16) double gtc[2][20];    // corrected condensed gradient of a stage (corrector sweep, one stage ahead)
+    alignas(16) double xhat[12];
+    alignas(16) double u0[6];
+    alignas(16) double logv[48];
+    alignas(16) double logbuf[LOG_ROWS][SLOGB];
+};
+#ifndef MPCB_STREAM_WPE
+#define MPCB_STREAM_WPE 2
+#endif
+static_assert(sizeof(SSmem) <= 163840 / (4 * MPCB_STREAM_WPE), "MPCB_STREAM_WPE wavefronts per SIMD share the 160 KiB of a CU");
+
+#define SE_DEV __device__ __forceinline__
+#define SE_PASS __device__ __noinline__
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ __attribute__((aligned(16))) SSmem g_ssm;
+
+// ---- wave-level primitives (one wavefront = one simulation: no workgroup barrier anywhere) ----
+SE_DEV void fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int CTRL>
+SE_DEV double dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+SE_DEV double lane_val(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <class Op>
+SE_DEV double wave_reduce(double v, Op op)
+{
+    v = op(v, dpp<0xB1>(v));
+    v = op(v, dpp<0x4E>(v));
+    v = op(v, dpp<0x141>(v));
+    v = op(v, dpp<0x140>(v));
+    return op(op(lane_val(v, 0), lane_val(v, 16)), op(lane_val(v, 32), lane_val(v, 48)));
+}
+struct OpSum { SE_DEV double operator()(double a, double b) const { return a + b; } };
+struct OpMax { SE_DEV double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { SE_DEV double operator()(double a, double b) const { return fmin(a, b); } };
+SE_DEV double wsum(double v) { return wave_reduce(v, OpSum()); }
+SE_DEV double wmax(double v) { return wave_reduce(v, OpMax()); }
+SE_DEV double wmin(double v) { return wave_reduce(v, OpMin()); }
+SE_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+SE_DEV double unid(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+SE_DEV double wclock() { return (double)wall_clock64() * 1e-8; }
+
+// --------------------------------------------------------------------------------------------- record bundles
+// A BUNDLE is what one stage of a pass reads (or writes): a few segments (byte ranges, multiples of 16 B) of the
+// stage's rows in the record groups, concatenated in LDS.  Lane l of copy instruction j moves 16-byte item
+// j*64+l; which segment the item belongs to, its address in row 0 and the row stride are worked out once per pass.
+struct Seg {
+    char *base;     // group array, row 0
+    int ld;         // row stride (bytes)
+    int off, w;     // byte range inside the row (multiples of 16)
+};
+SE_DEV Seg segd(double *base, int ld, int c0, int w) { Seg s; s.base = (char *)base; s.ld = ld * 8; s.off = c0 * 8; s.w = w * 8; return s; }
+template <class FT>
+SE_DEV Seg segf(char *base, int c0, int w) { Seg s; s.base = base; s.ld = SW4 * (int)sizeof(FT); s.off = c0 * (int)sizeof(FT); s.w = w * (int)sizeof(FT); return s; }
+
+template <int NI>
+struct Bundle {
+    MPC_GLOBAL char *g[NI];   // this lane's item in row 0 (nullptr: lane idle in this instruction)
+    int stride[NI];           // bytes per row
+    template <int NS>
+    SE_DEV void setup(const Seg (&s)[NS], int lane)
+    {
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int e = j * WAVE + lane;
+            g[j] = nullptr;
+            stride[j] = 0;
+            int cum = 0;
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int n = s[i].w / 16;
+                if (e >= cum && e < cum + n) {
+                    g[j] = (MPC_GLOBAL char *)(s[i].base + s[i].off) + (size_t)(e - cum) * 16;
+                    stride[j] = s[i].ld;
+                }
+                cum += n;
+            }
+        }
+    }
+};
+// Asynchronous fetch of row k of a bundle straight into LDS (global_load_lds_dwordx4: no VGPR destination, the data
+// land at slot + j KiB + lane * 16 B; completion is visible only through vmcnt).
+template <int NI>
+SE_DEV void dma_issue(const Bundle<NI> &b, int k, double *slot)
+{
+#pragma unroll
+    for (int j = 0; j < NI; j++)
+        if (b.g[j])
+            __builtin_amdgcn_global_load_lds((const MPC_GLOBAL void *)(b.g[j] + (long long)k * b.stride[j]),
+                                             (MPC_LOCAL void *)(slot + j * 2 * WAVE), 16, 0, 0);
+}
+template <int NI>
+SE_DEV void store_out(const Bundle<NI> &b, int k, const double *lds, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < NI; j++)
+    {
+#ifndef MPCB_NOSTORE
+        if (b.g[j]) *(MPC_GLOBAL D2 *)(b.g[j] + (long long)k * b.stride[j]) = ((const MPC_LOCAL D2 *)lds)[j * WAVE + lane];
+#endif
+    }
+}
+constexpr int ni_of(int bytes) { return (bytes / 16 + WAVE - 1) / WAVE; }
+
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+template <int n>
+SE_DEV void wait_vm()
+{
+    static_assert(n >= 0 && n < 64, "vmcnt is six bits wide");
+    __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14));
+}
+
+// Sweep driver: calls body(k, ring) for the rows k of a forward (0..N) or backward (N..0) sweep with row k and the
+// NEXT row of the sweep landed in the ring (the row before is still valid as well), while D further rows are in
+// flight.  Vector-memory operations complete in issue order (MI355X_MICROARCH.md, s_waitcnt), so "row i+1 has landed"
+// is a counted wait on what was issued after it: D-1 fetches of NI instructions and D-1 stores of NO instructions in the
+// steady state -- fewer stores in the first D stages, fewer fetches in the last D, where the smaller (safe) count is used.
+// The fetch of row i+1+D is issued after stage i has been computed: it overwrites the slot of row i-1.
+struct Ring {
+    int slot_doubles, slots;
+    SE_DEV double *row(int k) const { return g_ssm.ring + (k % slots) * slot_doubles; }
+};
+template <int NI>
+SE_DEV Ring make_ring()
+{
+    Ring rg;
+    rg.slot_doubles = NI * 2 * WAVE;
+    rg.slots = RING_DOUBLES / rg.slot_doubles > 12 ? 12 : RING_DOUBLES / rg.slot_doubles;
+    return rg;
+}
+template <int NI, int NO, bool BACK, class F>
+SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
+{
+    constexpr int SLOT = NI * 2 * WAVE;                      // doubles (whole copy pieces)
+    constexpr int SLOTS = RING_DOUBLES / SLOT > 12 ? 12 : RING_DOUBLES / SLOT;
+    constexpr int D = SLOTS - 2;
+    static_assert(D >= 1, "ring too small for this bundle");
+    // issue order per stage: [wait] compute, stores of row i, fetch of row i+1+D
+    constexpr int W_STEADY = (D - 1) * (NI + NO), W_EARLY = (D - 1) * NI, W_LATE = (D - 1) * NO;
+    static_assert(W_STEADY < 64, "vmcnt range");
+    const Ring rg = make_ring<NI>();
+    auto row = [&](int i) { return BACK ? N - i : i; };
+    (void)lane;
+    wait_vm<0>();                                            // nothing of an earlier pass is in flight
+    fence();
+    for (int j = 0; j <= D; j++)
+        if (j <= N) dma_issue(bin, row(j), rg.row(row(j)));
+    if (N + 1 <= D) wait_vm<0>();                            // short horizon: everything was issued above
+    for (int i = 0; i <= N; i++) {
+        if (N + 1 > D) {
+            if (i + 1 > N) wait_vm<0>();
+            else if (i + D > N) { if (i < D) wait_vm<0>(); else wait_vm<W_LATE>(); }
+            else if (i < D) wait_vm<(W_EARLY < W_STEADY ? W_EARLY : W_STEADY)>();
+            else wait_vm<W_STEADY>();
+        }
+        fence();
+        body(row(i), rg);
+        if (i + 1 + D <= N) dma_issue(bin, row(i + 1 + D), rg.row(row(i + 1 + D)));
+    }
+}
+
+// Stationarity element of class CLS (0: u_j, 1: q_j, 2: v_j) -- mpc_core.h Engine::stat_cls with the records in LDS.
+// r1: G1 row of stage k, r2: [R..GV] of stage k, pk / pm: pi_k / pi_{k-1}.
+template <int CLS>
+SE_DEV double stat_cls(int N, int k, int j, const double *r1, const double *r2, bool with_delta, const double *pk, const double *pm)
+{
+    const InstParams &P = g_ssm.P;
+    double val = 0.0;
+    if (CLS == 0) {
+        if (k >= N) return 0.0;
+        double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+        if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
+        const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+        val = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
+        val += P.b1[j] * pk[j] + P.b2[j] * pk[6 + j];
+        if (with_delta) val += P.dt * P.lm * r1[O_QW + j];
+    } else if (CLS == 1) {
+        if (k == 0) return 0.0;
+        if (k < N) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
+            val = P.dt * s + pk[j];
+        }
+        if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 6 + j];
+        val -= pm[j];
+    } else {
+        if (k == 0) return 0.0;
+        if (k < N) {
+            double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+            if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
+            const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+            val = P.dt * (r2[O_GV + j] * r2[O_Y + 4] + c2 * (vj - uj));
+            val += P.a12[j] * pk[j] + P.a22[j] * pk[6 + j];
+        }
+        if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 12 + j];
+        val -= pm[6 + j];
+    }
+    return val;
+}
+
+struct IpmNorms {
+    double ng, nb, nd, nm, smu, nc;
+};
+
+// =============================================================================================== residual pass
+// MODE 0 (HPIPM warm start 2): keep (w, pi, lam, t) of the previous QP, clamp lam, t >= 0.1, embed x0.
+// MODE 1: apply the Newton step of length `a`.  Then QP residuals, Gamma, the condensed gradient gt and rb.
+// Forward sweep with one row of lookahead: stage k needs the UPDATED dw_{k+1} (dynamics residual) and the
+// multiplier step stored with stage k+1; pi_{k-1} travels in LDS from the previous iteration.
+//   in  : G1 row | G3 [DW..DT] | G2 [R..GV]            (234 doubles)
+//   out : G1 [QW..QT] | G2 [R,Y] | G2 [GAM|GT|RB] | G3 [RG|RD|RM]   (196 doubles)
+template <int MODE>
+SE_PASS IpmNorms residual_pass(double a)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    constexpr int I_D = 96, I_L = 174;                       // input image: G1 row | D | lin
+    constexpr int O_W = 0, O_RY = 78, O_G = 88, O_3 = 130;   // output image
+    Bundle<2> bin, bout;
+    {
+        const Seg si[3] = {segd(w.G1, W1, 0, W1), segd(w.G3, W3, O_DW, 78), segd(w.G2, W2, 0, W2_LIN)};
+        bin.setup(si, lane);
+        const Seg so[4] = {segd(w.G1, W1, O_QW, 78), segd(w.G2, W2, 0, 10), segd(w.G2, W2, O_GAM, 42), segd(w.G3, W3, 0, 66)};
+        bout.setup(so, lane);
+    }
+    double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0, ncl = 0;
+    // update of one landed row: dw += a ddw ; (lam, t) += a (dlam, dt) -- or the warm-start clamp in mode 0
+    auto upd_row = [&](double *row, int kr) {
+        if (MODE == 1) {
+            if (lane < NW) row[O_QW + lane] += a * row[I_D + lane];
+        } else {
+            if (kr == 0 && lane < NX) row[O_QW + 6 + lane] = sm.xhat[lane] - row[O_X + lane];
+            if (kr == N && lane >= 12 && lane < 18) row[O_QW + lane - 12] = 0.0;
+        }
+        if (lane >= 18 && lane < 30) {
+            const int j = lane - 18;
+            const bool hc = has_comp(N, kr, j);
+            const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+            double *lam = row + O_QLAM, *t = row + O_QT;
+            if (MODE == 0) {
+                if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
+                else { lam[j] = 0.0; t[j] = 1.0; }
+                if (bhi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); }
+                else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
+            } else {
+                const double *dl = row + I_D + 30, *dt = row + I_D + 54;
+                const double l0 = lam[j], t0 = t[j], l1 = lam[12 + j], t1 = t[12 + j];
+                const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
+                if (blo) { lam[j] = fmax(l0 + a * d0, 1e-16); t[j] = fmax(t0 + a * e0, 1e-16); }
+                if (bhi) { lam[12 + j] = fmax(l1 + a * d1, 1e-16); t[12 + j] = fmax(t1 + a * e1, 1e-16); }
+            }
+        }
+    };
+    if (lane < NX) sm.vec[0][lane] = 0.0;      // pi_{-1}: never read (k = 0 rows return early)
+    sweep<2, 2, false>(bin, N, lane, [&](int k, const Ring &rg) {
+        double *cur = rg.row(k), *nxt = rg.row(k + 1);
+        double *o = sm.out[k & 1];
+        if (k == 0) upd_row(cur, 0);
+        // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
+        if (k + 1 <= N) {
+            upd_row(nxt, k + 1);
+            if (MODE == 1 && lane >= 32 && lane < 44) cur[O_QPI + lane - 32] += a * nxt[I_D + 18 + lane - 32];
+        }
+        fence();
+        // ---- Y: y_i = w_i (r_i + G_i . delta_k)
+        if (lane < NTASK && k < N) {
+            const double *r2 = cur + I_L, *dw = cur + O_QW;
+            double v = r2[O_R + lane];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v += r2[O_GQ + lane * 6 + j] * dw[6 + j];
+            if (lane == 4) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
+            }
+            cur[I_L + O_Y + lane] = P.w_task[lane] * v;
+        }
+        fence();
+        // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29), copies (lanes 32..)
+        {
+            const double *r1 = cur, *r2 = cur + I_L;
+            const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
+            if (lane < NW) {
+                const int cls = lane / 6, j = lane - cls * 6, ci = lane;
+                double rg = cls == 0 ? stat_cls<0>(N, k, j, r1, r2, true, pk, pm)
+                          : cls == 1 ? stat_cls<1>(N, k, j, r1, r2, true, pk, pm) : stat_cls<2>(N, k, j, r1, r2, true, pk, pm);
+                double gt = rg;
+                if (cls < 2) {
+                    const bool hc = has_comp(N, k, ci);
+                    const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                    const double v_ = r1[cls == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
+                    double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                    const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
+                    const double b_lo = bnd_lo(P, ci), b_hi = bnd_hi(P, ci);
+                    if (blo) {
+                        const double l = l_lo, t = t_lo, it = fast_rcp(t);
+                        rdl = dv - (b_lo - v) - t;
+                        rml = l * t;
+                        rg -= l; gt -= l;
+                        gam += l * it;
+                        gt += (rml + l * rdl) * it;
+                        a_mu += rml;
+                        a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                    }
+                    if (bhi) {
+                        const double l = l_hi, t = t_hi, it = fast_rcp(t);
+                        rdu = (b_hi - v) - dv - t;
+                        rmu = l * t;
+                        rg += l; gt += l;
+                        gam += l * it;
+                        gt -= (rmu + l * rdu) * it;
+                        a_mu += rmu;
+                        a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
+                    }
+                    o[O_3 + O_RD + ci] = rdl; o[O_3 + O_RD + 12 + ci] = rdu;
+                    o[O_3 + O_RM + ci] = rml; o[O_3 + O_RM + 12 + ci] = rmu;
+                    o[O_G + ci] = gam;
+                }
+                o[O_3 + O_RG + ci] = rg;
+                o[O_G + 12 + ci] = gt;
+                a_g = fmax(a_g, fabs(rg));
+            } else if (lane < 30) {
+                const int i = lane - 18;
+                double v = 0.0;
+                if (k < N) {
+                    const double *dw = cur + O_QW, *dn = nxt + O_QW;
+                    if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
+                    else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
+                    v += r2[O_BD + i] - dn[6 + i];
+                    a_b = fmax(a_b, fabs(v));
+                }
+                o[O_G + 30 + i] = v;
+            }
+        }
+        fence();
+        // the updated QW..QT of this stage and r, y go out with the residual records; pi_k for the next stage
+        if (lane < 39) ((MPC_LOCAL D2 *)(o + O_W))[lane] = ((MPC_LOCAL D2 *)(cur + O_QW))[lane];
+        else if (lane < 44) ((MPC_LOCAL D2 *)(o + O_RY))[lane - 39] = ((MPC_LOCAL D2 *)(cur + I_L))[lane - 39];
+        else if (lane >= 48 && lane < 60) sm.vec[(k + 1) & 1][lane - 48] = cur[O_QPI + lane - 48];
+        fence();
+        store_out(bout, k, o, lane);
+    });
+    IpmNorms r;
+    r.ng = wmax(a_g); r.nb = wmax(a_b); r.nd = wmax(a_d); r.nm = wmax(a_m); r.smu = wsum(a_mu); r.nc = wsum(ncl);
+    return r;
+}
+
+// =============================================================================================== factorisation sweep
+// Backward Riccati sweep, matrix AND vector recursion of a stage in the same two phases (mpc_core.h fact_pass):
+//   lanes 0..35  block (a,b) of the 12x12 cost-to-go in registers for the whole sweep
+//   lanes 0..17  one right-hand side of the 6x6 LDL' each (12 columns of S~ -> K, 6 of I -> R~^-1)
+//   lanes 40..51 vector recursion: t = p_{k+1} + P_{k+1} rb_k ; h_u ; p_k ; R~^-1 h_u ; e
+//   in  : G2 [GQ..RB] (78 doubles; row k-1 one stage ahead for Gamma_u)     out : factor row (SW4 x FT)
+template <class FT>
+struct FactLane {
+    FT b1a, b2a, b1b, b2b, a12a, a22a, a12b, a22b;
+    FT hu_c, huv_c, lm_c;
+    FT mqq, mqv, mvq, mvv;
+    FT qqq, qqv, qvq, qvv;
+    int a, b, oqq, oqv, ovv;
+};
+
+template <class FT>
+SE_PASS void fact_pass()
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    constexpr int NIO = ni_of(SW4 * (int)sizeof(FT));
+    Bundle<1> bin;
+    Bundle<NIO> bout;
+    {
+        const Seg si[1] = {segd(w.G2, W2, O_GQ, 78)};
+        bin.setup(si, lane);
+        const Seg so[1] = {segf<FT>(w.G4, 0, SW4)};
+        bout.setup(so, lane);
+    }
+    FactLane<FT> f;
+    {
+        const int a = lane < 36 ? lane / 6 : 0, b = lane < 36 ? lane % 6 : 0;
+        f.a = a; f.b = b;
+        f.oqq = tri(imin(a, b), imax(a, b)); f.oqv = tri(a, 6 + b); f.ovv = tri(6 + imin(a, b), 6 + imax(a, b));
+        f.b1a = (FT)P.b1[a]; f.b2a = (FT)P.b2[a]; f.b1b = (FT)P.b1[b]; f.b2b = (FT)P.b2[b];
+        f.a12a = (FT)P.a12[a]; f.a22a = (FT)P.a22[a]; f.a12b = (FT)P.a12[b]; f.a22b = (FT)P.a22[b];
+        const double c2 = P.dt * P.w_qddot * P.cq[a] * P.cq[a];
+        f.hu_c = (FT)(a == b ? P.dt * 2.0 * P.w_u + c2 + P.dt * P.lm : 0.0);
+        f.huv_c = (FT)(a == b ? c2 : 0.0);
+        f.lm_c = (FT)(a == b ? P.dt * P.lm : 0.0);
+        f.mqq = f.mqv = f.mvq = f.mvv = (FT)0;
+        f.qqq = f.qqv = f.qvq = f.qvv = (FT)0;
+    }
+    const FT dw0 = (FT)(P.dt * P.w_task[0]), dw1 = (FT)(P.dt * P.w_task[1]), dw2 = (FT)(P.dt * P.w_task[2]),
+             dw3 = (FT)(P.dt * P.w_task[3]), dw4 = (FT)(P.dt * P.w_task[4]);
+    const int jv = lane >= 40 && lane < 52 ? lane - 40 : 0;      // vector lanes: component
+    const FT va12 = (FT)P.a12[jv % 6], va22 = (FT)P.a22[jv % 6];
+    const FT vb = (FT)(jv < 6 ? P.b1[jv] : P.b2[jv - 6]);         // the lane's row of B
+    FT b1r[6], b2r[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { b1r[i] = (FT)P.b1[i]; b2r[i] = (FT)P.b2[i]; }
+    FT pr = (FT)0;                                                // vector lanes: p_{k+1}[jv]
+    int sb = 0;
+    auto next_stage = [&](FT gam_u, int sbw) {
+        const FT fq = f.b1a * f.mqq + f.b2a * f.mvq, fv = f.b1a * f.mqv + f.b2a * f.mvv;
+        FT r = fq * f.b1b + fv * f.b2b + f.hu_c;
+        r += f.a == f.b ? gam_u : (FT)0;
+        sm.Rt[f.a * 6 + f.b] = (double)r;
+        double *St = sm.St2[sbw];
+        St[f.a * 12 + f.b] = (double)fq;
+        St[f.a * 12 + 6 + f.b] = (double)(fq * f.a12b + fv * f.a22b - f.huv_c);
+        const FT cq = f.a12a * f.mqq + f.a22a * f.mvq, cv = f.a12a * f.mqv + f.a22a * f.mvv;
+        f.qqq = f.mqq;
+        f.qqv = f.mqq * f.a12b + f.mqv * f.a22b;
+        f.qvq = cq;
+        f.qvv = cq * f.a12b + cv * f.a22b;
+    };
+    sweep<1, NIO, true>(bin, N, lane, [&](int k, const Ring &rg) {
+        const double *ric = rg.row(k);
+        const double *ricd = rg.row(k > 0 ? k - 1 : 0);           // row k-1 (valid for k >= 1)
+        MPC_LOCAL FT *fac = (MPC_LOCAL FT *)sm.out[k & 1];
+        const MPC_LOCAL FT *facn = (const MPC_LOCAL FT *)sm.out[(k + 1) & 1];   // row k+1 (valid for k < N)
+        const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
+        if (k == N) {
+            // terminal stage: no cost, no bounds -> P_N = lm I ; p_N = gt_x ; R~, S~ of stage N-1
+            const FT lmN = (FT)P.lm;
+            for (int e = lane; e < SW4; e += WAVE) fac[e] = (FT)0;
+            fence();
+            if (lane < NX) fac[SPM + tri(lane, lane)] = lmN;
+            if (lane < 36) {
+                f.mqv = f.mvq = (FT)0;
+                f.mqq = f.mvv = f.a == f.b ? lmN : (FT)0;
+                if (k >= 1) next_stage((FT)ricd[36 + f.a], sb);
+            } else if (lane >= 40 && lane < 52) {
+                pr = (FT)gt[6 + jv];
+                fac[SPV + jv] = pr;
+                sm.vec[0][jv] = (double)pr;
+            }
+            fence();
+            store_out(bout, k, sm.out[k & 1], lane);
+            return;
+        }
+        // ---- B: LDL' (right-looking, redundant in every lane) + one right-hand side per lane ; vector lanes: t
+        {
+            const double *St = sm.St2[sb];
+            FT A_[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) A_[i][j] = (FT)sm.Rt[i * 6 + j];
+            FT dinv[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                dinv[j] = sizeof(FT) == 8 ? (FT)fast_rcp((double)A_[j][j]) : (FT)1 / A_[j][j];
+                FT lj[6];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) lj[i] = A_[i][j] * dinv[j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int r = j + 1; r <= i; r++) A_[i][r] -= lj[i] * A_[r][j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) A_[i][j] = lj[i];
+            }
+            if (lane < 18) {
+                FT x[6];
+                const int col = lane < 12 ? lane : 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] = (FT)St[i * 12 + col];
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] = lane < 12 ? x[i] : (i == lane - 12 ? (FT)1 : (FT)0);
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int i = j + 1; i < 6; i++) x[i] -= A_[i][j] * x[j];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] *= dinv[i];
+#pragma unroll
+                for (int j = 5; j >= 0; j--) {
+#pragma unroll
+                    for (int i = 0; i < j; i++) x[i] -= A_[j][i] * x[j];
+                }
+                if (lane < 12) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { fac[SK + i * 12 + lane] = x[i]; sm.Kf[i * 12 + lane] = (double)x[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) fac[SRI + i * 6 + (lane - 12)] = x[i];
+                }
+            } else if (lane >= 40 && lane < 52) {
+                // t = p_{k+1} + P_{k+1} rb_k
+                FT w0 = (FT)0, w1 = (FT)0;
+#pragma unroll
+                for (int j = 0; j < NX; j += 2) { w0 += facn[SPM + tri_sym(jv, j)] * (FT)rbv[j]; w1 += facn[SPM + tri_sym(jv, j + 1)] * (FT)rbv[j + 1]; }
+                const FT wv = w0 + w1;
+                fac[SWV + jv] = wv;
+                sm.vec[1][jv] = (double)(pr + wv);
+            }
+        }
+        fence();
+        // ---- CA: P_k block, then R~ / S~ of stage k-1 ; vector lanes: h_u, p_k, R~^-1 h_u, e
+        if (lane < 36) {
+            if (k > 0) {
+                const double *St = sm.St2[sb];
+                const double *gq = ric, *gv = ric + 30;
+                FT sa[6], sva[6], kb[6], kvb[6];
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    sa[m] = (FT)St[m * 12 + f.a]; sva[m] = (FT)St[m * 12 + 6 + f.a];
+                    kb[m] = (FT)sm.Kf[m * 12 + f.b]; kvb[m] = (FT)sm.Kf[m * 12 + 6 + f.b];
+                }
+                const FT ga0 = (FT)gq[f.a], ga1 = (FT)gq[6 + f.a], ga2 = (FT)gq[12 + f.a], ga3 = (FT)gq[18 + f.a], ga4 = (FT)gq[24 + f.a];
+                const FT gb0 = (FT)gq[f.b], gb1 = (FT)gq[6 + f.b], gb2 = (FT)gq[12 + f.b], gb3 = (FT)gq[18 + f.b], gb4 = (FT)gq[24 + f.b];
+                const FT gva = (FT)gv[f.a], gvb = (FT)gv[f.b];
+                const FT gam_q = (FT)gam[6 + f.a], gam_u = (FT)ricd[36 + f.a];
+                FT pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4) + f.lm_c;
+                FT pqv = f.qqv + dw4 * ga4 * gvb;
+                FT pvq = f.qvq + dw4 * gva * gb4;
+                FT pvv = f.qvv + dw4 * gva * gvb + (f.huv_c + f.lm_c);
+                pqq += f.a == f.b ? gam_q : (FT)0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    pqq -= sa[m] * kb[m]; pqv -= sa[m] * kvb[m];
+                    pvq -= sva[m] * kb[m]; pvv -= sva[m] * kvb[m];
+                }
+                f.mqq = pqq; f.mqv = pqv; f.mvq = pvq; f.mvv = pvv;
+                if (f.a <= f.b) { fac[SPM + f.oqq] = pqq; fac[SPM + f.ovv] = pvv; }
+                fac[SPM + f.oqv] = pqv;
+                next_stage(gam_u, sb ^ 1);
+            }
+        } else if (lane >= 40 && lane < 52) {
+            // (register arrays are only ever indexed by constants: a lane-dependent index would put them in scratch memory,
+            // and a scratch load in the stage loop drains every fetch in flight)
+            FT hu[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) hu[m] = (FT)gt[m] + b1r[m] * (FT)sm.vec[1][m] + b2r[m] * (FT)sm.vec[1][6 + m];
+            const FT t = (FT)sm.vec[1][jv];
+            const FT oq = (FT)sm.vec[1][jv >= 6 ? jv - 6 : jv];
+            FT pj = (FT)gt[6 + jv] + (jv < 6 ? t : va12 * oq + va22 * t);
+            FT s0 = (FT)0, s1 = (FT)0;
+#pragma unroll
+            for (int m = 0; m < 6; m += 2) { s0 += (FT)sm.Kf[m * 12 + jv] * hu[m]; s1 += (FT)sm.Kf[(m + 1) * 12 + jv] * hu[m + 1]; }
+            pj -= s0 + s1;
+            pr = pj;
+            fac[SPV + jv] = pj;
+            const int i6 = jv < 6 ? jv : jv - 6;
+            FT v0 = (FT)0, v1 = (FT)0;
+#pragma unroll
+            for (int m = 0; m < 6; m += 2) { v0 += fac[SRI + i6 * 6 + m] * hu[m]; v1 += fac[SRI + i6 * 6 + m + 1] * hu[m + 1]; }
+            const FT vh = v0 + v1;
+            if (jv < 6) fac[SVH + jv] = vh;
+            fac[SEo + jv] = (FT)rbv[jv] - vb * vh;
+        } else if (lane >= 52 && lane < 56) {
+            // padding scalars of the record: defined values
+            if (lane < 54) fac[SVH + 6 + (lane - 52)] = (FT)0;
+            else fac[SPM + 78 + (lane - 54)] = (FT)0;
+        }
+        sb ^= 1;
+        fence();
+        store_out(bout, k, sm.out[k & 1], lane);
+    });
+}
+
+// =============================================================================================== forward sweeps
+// du = -K dx - R~^-1 h_u ; dx+ = e + A dx - B K dx ; dpi = p + P dx ; dlam, dt (HPIPM compute_lam_t), largest
+// feasible step, the three centering sums.  One phase per stage, four roles at once:
+//   lanes 0..11  dx_{k+1}           lanes 16..21  du_k           lanes 32..43  dpi_{k-1} (final sweep only)
+//   lanes 48..59 dlam, dt, step length and sums of stage k-1 (its du / dx were written one phase earlier)
+//   in  : factor [K..E] or [K..P] | G1 [QLAM,QT] | G3 [RD,RM]      out : G3 [DLAM,DT] (affine) or [DW..DT]
+struct StepInfo {
+    double alpha, S0, S1, S2;
+};
+template <class FT, bool AFFINE>
+SE_PASS StepInfo forward_pass()
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    constexpr int LF = AFFINE ? SW4_AFF : SW4_FWD;
+    constexpr int FB = LF * (int)sizeof(FT);                       // bytes of the factor part
+    constexpr int NII = ni_of(FB + 96 * 8);
+    constexpr int I_LT = FB / 8, I_R = I_LT + 48;                  // doubles
+    Bundle<NII> bin;
+    Bundle<1> bout;
+    {
+        const Seg si[3] = {segf<FT>(w.G4, 0, LF), segd(w.G1, W1, O_QLAM, 48), segd(w.G3, W3, O_RD, 48)};
+        bin.setup(si, lane);
+        if (AFFINE) { const Seg so[1] = {segd(w.G3, W3, O_DLAM, 48)}; bout.setup(so, lane); }
+        else { const Seg so[1] = {segd(w.G3, W3, O_DW, 78)}; bout.setup(so, lane); }
+    }
+    const int j12 = lane & 15;                                     // component of the 12-lane roles
+    const int j6 = j12 % 6;
+    const FT a12 = (FT)P.a12[j6], a22 = (FT)P.a22[j6], b1 = (FT)P.b1[j6], b2 = (FT)P.b2[j6];
+    double al = 1.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
+    auto stage = [&](int k, const Ring &rg) {
+        const double *row = rg.row(k), *rowp = rg.row(k > 0 ? k - 1 : 0);
+        const MPC_LOCAL FT *fac = (const MPC_LOCAL FT *)row;
+        double *o = sm.out[k & 1], *op = sm.out[(k + 1) & 1];
+        const double *dxk = sm.vec[k & 1];
+        if (lane < 12 && k <= N) {
+            const int i = lane < 6 ? lane : lane - 6;
+            FT s0 = (FT)0, s1 = (FT)0;
+#pragma unroll
+            for (int j = 0; j < NX; j += 2) { s0 += fac[SK + i * 12 + j] * (FT)dxk[j]; s1 += fac[SK + i * 12 + j + 1] * (FT)dxk[j + 1]; }
+            const FT kd = s0 + s1, own = (FT)dxk[lane], ov = (FT)dxk[lane < 6 ? lane + 6 : lane];
+            const FT v = fac[SEo + lane] + (lane < 6 ? own + a12 * ov - b1 * kd : a22 * own - b2 * kd);
+            o[6 + lane] = (double)own;                              // dx_k
+            sm.vec[(k + 1) & 1][lane] = (double)v;                  // dx_{k+1}
+        } else if (lane >= 16 && lane < 22 && k <= N) {
+            const int j = lane - 16;
+            double dv = 0.0;
+            if (k < N) {
+                FT s0 = fac[SVH + j], s1 = (FT)0;
+#pragma unroll
+                for (int i = 0; i < NX; i += 2) { s0 += fac[SK + j * 12 + i] * (FT)dxk[i]; s1 += fac[SK + j * 12 + i + 1] * (FT)dxk[i + 1]; }
+                dv = -(double)(s0 + s1);
+            }
+            o[j] = dv;                                              // du_k (stage N has no input: 0)
+        } else if (!AFFINE && lane >= 32 && lane < 44 && k <= N) {
+            const int j = lane - 32;
+            double v = 0.0;
+            if (k >= 1) {
+                FT s0 = fac[SPV + j], s1 = (FT)0;
+#pragma unroll
+                for (int i = 0; i < NX; i += 2) { s0 += fac[SPM + tri_sym(j, i)] * (FT)dxk[i]; s1 += fac[SPM + tri_sym(j, i + 1)] * (FT)dxk[i + 1]; }
+                v = (double)(s0 + s1);
+            }
+            o[18 + j] = v;                                          // DPI slot of stage k holds dpi_{k-1}
+        } else if (lane >= 48 && lane < 60 && k >= 1) {
+            const int j = lane - 48, kp = k - 1;
+            const double *lt = rowp + I_LT, *r = rowp + I_R;
+            const double dv = j < 6 ? op[j] : op[6 + (j - 6)];       // du_{k-1}[j] or dq_{k-1}[j-6]
+            const bool hc = has_comp(N, kp, j);
+            const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+            const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
+            const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
+            double dtl = 0, dll = 0, dtu = 0, dlu = 0;
+            if (blo) {
+                dtl = dv + rdl;
+                dll = -(rml + ll * dtl) * fast_rcp(tl);
+                if (dll < 0 && ll + al * dll < 0) al = -ll * fast_rcp(dll);
+                if (dtl < 0 && tl + al * dtl < 0) al = -tl * fast_rcp(dtl);
+                a0 += ll * tl; a1 += ll * dtl + tl * dll; a2 += dll * dtl;
+            }
+            if (bhi) {
+                dtu = -dv + rdu;
+                dlu = -(rmu + lu * dtu) * fast_rcp(tu);
+                if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
+                if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
+                a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
+            }
+            op[30 + j] = dll; op[42 + j] = dlu;
+            op[54 + j] = dtl; op[66 + j] = dtu;
+        }
+        fence();
+        if (k >= 1) store_out(bout, k - 1, AFFINE ? op + 30 : op, lane);
+    };
+    sweep<NII, 1, false>(bin, N, lane, stage);
+    fence();
+    stage(N + 1, make_ring<NII>());      // the lagging role's last stage
+    StepInfo s;
+    s.alpha = wmin(al); s.S0 = wsum(a0); s.S1 = wsum(a1); s.S2 = wsum(a2);
+    return s;
+}
+
+// =============================================================================================== corrector + backward solve
+// Centering-corrector right-hand side (HPIPM compute_centering_correction) and the backward SOLVE sweep on the
+// existing factor:  t = p_{k+1} + w_k ; h_u = gt_u + B' t ; p_k = gt_x + A' t - K' h_u ; R~^-1 h_u ; e.
+// Two phases per stage; the corrected gradient of stage k-1 is formed (lanes 32..43) while stage k is solved.
+//   in  : G1 [QLAM,QT] | G3 [RG,RD] | G3 [DLAM,DT] | G2 [GT,RB] | factor K | factor [w, R~^-1]
+//   out : G3 RM | factor [R~^-1 h_u, e, p]
+template <class FT>
+SE_PASS void corrector_pass(double sigma_mu)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    constexpr int I_3 = 48, I_DL = 90, I_GB = 138, I_F = 168;      // doubles: lam,t | RG,RD | DLAM,DT | GT,RB | factor parts
+    constexpr int FBYTES = (72 + 48) * (int)sizeof(FT);
+    constexpr int NII = ni_of(168 * 8 + FBYTES);
+    constexpr int OB = 24 * 8 + 32 * (int)sizeof(FT);
+    Bundle<NII> bin;
+    Bundle<1> bout;
+    {
+        const Seg si[6] = {segd(w.G1, W1, O_QLAM, 48), segd(w.G3, W3, 0, 42), segd(w.G3, W3, O_DLAM, 48), segd(w.G2, W2, O_GT, 30),
+                           segf<FT>(w.G4, SK, 72), segf<FT>(w.G4, SWV, 48)};
+        bin.setup(si, lane);
+        const Seg so[2] = {segd(w.G3, W3, O_RM, 24), segf<FT>(w.G4, SVH, 32)};
+        bout.setup(so, lane);
+        (void)OB;
+    }
+    const int j12 = lane & 15, j6 = j12 % 6;
+    const FT va12 = (FT)P.a12[j6], va22 = (FT)P.a22[j6];
+    // corrector of one landed row -> sm.gtc[kr & 1] (18 entries) and the RM slot of that row's output image
+    auto corr_row = [&](const double *row, int kr, int j) {
+        const double *lt = row, *r3 = row + I_3, *dl = row + I_DL, *gtb = row + I_GB;
+        double *og = sm.gtc[kr & 1], *rmo = sm.out[kr & 1];
+        const bool hc = has_comp(N, kr, j);
+        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+        const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
+        const double dll = dl[j], dtl = dl[24 + j], dlu = dl[12 + j], dtu = dl[36 + j];
+        const double rdl = r3[18 + j], rdu = r3[18 + 12 + j];
+        double gt = r3[j];
+        const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
+        const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
+        gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
+        gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+        og[j] = hc ? gt : gtb[j];
+        if (j < 6) og[12 + j] = gtb[12 + j];
+        rmo[j] = rml; rmo[12 + j] = rmu;
+    };
+    sweep<NII, 1, true>(bin, N, lane, [&](int k, const Ring &rg) {
+        const double *row = rg.row(k), *rowd = rg.row(k > 0 ? k - 1 : 0);
+        if (k == N) {
+            if (lane >= 32 && lane < 44) corr_row(row, N, lane - 32);
+            fence();
+        }
+        const double *gtc = sm.gtc[k & 1], *gtb = row + I_GB;
+        const MPC_LOCAL FT *kf = (const MPC_LOCAL FT *)(row + I_F), *wv = kf + 72, *ri = kf + 84;
+        double *o = sm.out[k & 1];
+        MPC_LOCAL FT *ofac = (MPC_LOCAL FT *)(o + 24);             // [VH 6 +2 | E 12 | PV 12]
+        const double *pn = sm.vec[(k + 1) & 1];                     // p_{k+1}
+        // ---- X: h_u (lanes 0..5) ; corrector of row k-1 (lanes 32..43)
+        if (lane < 6 && k < N) {
+            const FT t0 = (FT)pn[lane] + wv[lane], t1 = (FT)pn[6 + lane] + wv[6 + lane];
+            sm.vec[2][lane] = (double)((FT)gtc[lane] + (FT)P.b1[lane] * t0 + (FT)P.b2[lane] * t1);
+        } else if (lane >= 32 && lane < 44 && k >= 1) {
+            corr_row(rowd, k - 1, lane - 32);
+        }
+        fence();
+        // ---- Y: p_k (lanes 0..11), R~^-1 h_u and e (lanes 16..27)
+        if (lane < 12) {
+            FT pj;
+            if (k == N) {
+                pj = (FT)gtc[6 + lane];
+            } else {
+                const FT t = (FT)pn[lane] + wv[lane];
+                const FT oq = lane >= 6 ? (FT)pn[lane - 6] + wv[lane - 6] : (FT)0;
+                FT s0 = (FT)0, s1 = (FT)0;
+#pragma unroll
+                for (int m = 0; m < 6; m += 2) { s0 += kf[m * 12 + lane] * (FT)sm.vec[2][m]; s1 += kf[(m + 1) * 12 + lane] * (FT)sm.vec[2][m + 1]; }
+                pj = (FT)gtc[6 + lane] + (lane < 6 ? t : va12 * oq + va22 * t) - (s0 + s1);
+            }
+            sm.vec[k & 1][lane] = (double)pj;
+            ofac[20 + lane] = pj;
+        } else if (lane >= 16 && lane < 28) {
+            const int j = lane - 16, i6 = j < 6 ? j : j - 6;
+            FT vh = (FT)0, e = (FT)0;
+            if (k < N) {
+                FT v0 = (FT)0, v1 = (FT)0;
+#pragma unroll
+                for (int m = 0; m < 6; m += 2) { v0 += ri[i6 * 6 + m] * (FT)sm.vec[2][m]; v1 += ri[i6 * 6 + m + 1] * (FT)sm.vec[2][m + 1]; }
+                vh = v0 + v1;
+                e = (FT)gtb[18 + j] - (FT)(j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
+            }
+            if (j < 6) ofac[j] = vh;
+            ofac[8 + j] = e;
+        } else if (lane >= 28 && lane < 30) {
+            ofac[6 + (lane - 28)] = (FT)0;
+        }
+        fence();
+        store_out(bout, k, o, lane);
+    });
+}
+
+// =============================================================================================== IPM driver
+// HPIPM d_ocp_qp_ipm_solve main loop (mpc_core.h ipm_solve).  Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
+#ifdef MPCB_SPROF
+#define SPROF_T0(v) const double v = wclock()
+#define SPROF_ADD(i, v) if (threadIdx.x == 0) g_ssm.w.state[32 + (i)] += wclock() - v
+#else
+#define SPROF_T0(v)
+#define SPROF_ADD(i, v)
+#endif
+template <class FT>
+SE_DEV int ipm_solve(int qp_iter_max, int *iters_out)
+{
+    SSmem &sm = g_ssm;
+    const double tol = sm.P.qp_tol;
+    IpmNorms r = residual_pass<0>(0.0);
+    const double nc = unid(r.nc);
+    double mu = nc > 0 ? unid(r.smu) / nc : 0.0;
+    int it = 0, status = 1;
+    double alpha = 1.0;
+    for (;; it++) {
+        const double n0 = unid(r.ng), n1 = unid(r.nb), n2 = unid(r.nd), n3 = unid(r.nm);
+        int stop = -1;
+        if (n0 != n0 || n1 != n1 || n2 != n2 || n3 != n3) stop = 3;
+        else if (!(n0 > tol || n1 > tol || n2 > tol || n3 > tol)) stop = 0;
+        else if (it >= qp_iter_max) stop = 1;
+        else if (!(alpha > 1e-12)) stop = 2;
+        stop = uni(stop);
+        if (stop >= 0) { status = stop; break; }
+        SPROF_T0(tf);
+        fact_pass<FT>();
+        SPROF_ADD(0, tf);
+        const bool has_bounds = nc > 0;
+        if (has_bounds) {
+            SPROF_T0(ta);
+            const StepInfo sa = forward_pass<FT, true>();
+            SPROF_ADD(1, ta);
+            const double a_aff = unid(sa.alpha);
+            const double mu_aff = (unid(sa.S0) + a_aff * (unid(sa.S1) + a_aff * unid(sa.S2))) / nc;
+            const double tmp = mu_aff / mu;
+            const double sigma = tmp * tmp * tmp;
+            SPROF_T0(tc);
+            corrector_pass<FT>(sigma * mu);
+            SPROF_ADD(2, tc);
+            SPROF_T0(tw);
+            alpha = unid(forward_pass<FT, false>().alpha);
+            SPROF_ADD(3, tw);
+        } else {
+            alpha = unid(forward_pass<FT, false>().alpha);
+        }
+        const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
+        SPROF_T0(tr);
+        r = residual_pass<1>(a);
+        SPROF_ADD(4, tr);
+        mu = nc > 0 ? unid(r.smu) / nc : 0.0;
+    }
+#ifdef MPCB_SPROF
+    if (threadIdx.x == 0) g_ssm.w.state[32 + 7] += it;
+#endif
+    *iters_out = it;
+    return status;
+}
+
+// =============================================================================================== NLP passes (SQP_RTI)
+// Linearisation: lane <-> stage, straight from / to HBM (once per MPC step; each lane's 41 outputs land in its own
+// stage record, the L2 merges them into full lines).  Optionally applies the QP step first.
+SE_PASS void lin_pass(double alpha, bool do_update)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const Robot &rb = sm.rb;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    for (int k0 = 0; k0 <= N; k0 += WAVE) {
+        const int k = k0 + lane;
+        if (k > N) continue;
+        MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)(w.G1 + (size_t)k * W1);
+        MPC_GLOBAL double *r2 = (MPC_GLOBAL double *)(w.G2 + (size_t)k * W2);
+        double xx[12], uu[6];
+#pragma unroll
+        for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i];
+        if (do_update) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { xx[i] += alpha * r1[O_QW + 6 + i]; r1[O_X + i] = xx[i]; }
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { uu[i] += alpha * r1[O_QW + i]; r1[O_U + i] = uu[i]; }
+            }
+        }
+        double rec[W2_LIN];
+        if (k < N) {
+            task_lin<true>(rb, P, xx, xx + 6, rec);
+#pragma unroll
+            for (int i = 0; i < NTASK; i++) rec[O_Y + i] = P.w_task[i] * rec[O_R + i];
+#pragma unroll
+            for (int i = 0; i < 10; i++) r2[i] = rec[i];
+#pragma unroll
+            for (int i = O_GQ; i < W2_LIN; i++) r2[i] = rec[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) r2[i] = 0.0;
+#pragma unroll
+            for (int i = O_GQ; i < W2_LIN; i++) r2[i] = 0.0;
+        }
+    }
+}
+
+// Dynamics defect of the NLP iterate, cost = sum_k dt/2 r'Wr (acados get_cost()) and acados' ocp_nlp_res_compute
+// inf-norms [stat, eq, ineq, comp] with the QP multipliers (SQP_RTI).  Forward sweep, one row of lookahead (x_{k+1}).
+//   in : G1 row | G2 [R..GV]      out : G2 BD
+SE_PASS double nlp_res_pass(double *res4)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    constexpr int I_L = 96;
+    Bundle<2> bin;
+    Bundle<1> bout;
+    {
+        const Seg si[2] = {segd(w.G1, W1, 0, W1), segd(w.G2, W2, 0, W2_LIN)};
+        bin.setup(si, lane);
+        const Seg so[1] = {segd(w.G2, W2, O_BD, 12)};
+        bout.setup(so, lane);
+    }
+    double csum = 0.0, a_s = 0, a_e = 0, a_i = 0, a_c = 0;
+    if (lane < NX) sm.vec[0][lane] = 0.0;
+    sweep<2, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
+        double *cur = rg.row(k), *nxt = rg.row(k + 1);
+        double *o = sm.out[k & 1];
+        const double *r1 = cur, *r2 = cur + I_L;
+        if (lane < 12) {
+            // dynamics defect (prediction_model.py:317-320) and this stage's share of the cost
+            double v = 0.0;
+            if (k < N) {
+                const int j = lane % 6;
+                const double xq = r1[O_X + j], xv = r1[O_X + 6 + j], uj = r1[O_U + j];
+                v = lane < 6 ? (xq + P.a12[j] * xv + P.b1[j] * uj) - nxt[O_X + j] : (P.a22[j] * xv + P.b2[j] * uj) - nxt[O_X + 6 + j];
+                a_e = fmax(a_e, fabs(v));
+                if (lane < 6) {
+                    const double qdd = P.cq[j] * (uj - xv);
+                    csum += 0.5 * P.dt * (2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd);
+                } else if (lane < 6 + NTASK) {
+                    const double r = r2[O_R + (lane - 6)];
+                    csum += 0.5 * P.dt * P.w_task[lane - 6] * r * r;
+                }
+            }
+            o[lane] = v;
+        } else if (lane >= 16 && lane < 34 && res4) {
+            const int ci = lane - 16, cls = ci / 6, j = ci - cls * 6;
+            const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
+            double v = cls == 0 ? stat_cls<0>(N, k, j, r1, r2, false, pk, pm)
+                     : cls == 1 ? stat_cls<1>(N, k, j, r1, r2, false, pk, pm) : stat_cls<2>(N, k, j, r1, r2, false, pk, pm);
+            if (ci < NB && has_comp(N, k, ci)) {
+                const double curv = r1[ci < 6 ? O_U + ci : O_X + ci - 6];
+                const double *lam = r1 + O_QLAM, *tt = r1 + O_QT;
+                if (bnd_lo(P, ci) > -BOUND_INF) {
+                    v -= lam[ci];
+                    a_i = fmax(a_i, fabs((bnd_lo(P, ci) - curv) + tt[ci]));
+                    a_c = fmax(a_c, fabs(lam[ci] * tt[ci]));
+                }
+                if (bnd_hi(P, ci) < BOUND_INF) {
+                    v += lam[12 + ci];
+                    a_i = fmax(a_i, fabs((curv - bnd_hi(P, ci)) + tt[12 + ci]));
+                    a_c = fmax(a_c, fabs(lam[12 + ci] * tt[12 + ci]));
+                }
+            }
+            if (ci >= 6 && k == 0) v = 0.0;
+            a_s = fmax(a_s, fabs(v));
+        } else if (lane >= 48 && lane < 60) {
+            if (k == 0 && res4) a_i = fmax(a_i, fabs(sm.xhat[lane - 48] - r1[O_X + lane - 48]));   // lbx_0 = ubx_0 = x_hat
+            sm.vec[(k + 1) & 1][lane - 48] = cur[O_QPI + lane - 48];
+        }
+        fence();
+        store_out(bout, k, o, lane);
+    });
+    const double cost = wsum(csum);
+    if (res4) { res4[0] = wmax(a_s); res4[1] = wmax(a_e); res4[2] = wmax(a_i); res4[3] = wmax(a_c); }
+    return cost;
+}
+
+// =============================================================================================== closed loop
+SE_DEV void log_flush(const Outputs &out, int inst, int T1, int c_lo, int c_hi)
+{
+    SSmem &sm = g_ssm;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < LOG_ROWS * SLOGB; e += WAVE) {
+        const int row = e / SLOGB, cc = (c_hi & ~(SLOGB - 1)) + (e & (SLOGB - 1));
+        if (cc < c_lo || cc > c_hi) continue;
+        double *dst = row < 12 ? out.z + ((size_t)inst * 12 + row) * T1
+                    : row < 18 ? out.u + ((size_t)inst * 6 + (row - 12)) * T1
+                    : row < 30 ? out.ee_pose + ((size_t)inst * 12 + (row - 18)) * T1
+                    : row < 33 ? out.ee_rpy + ((size_t)inst * 3 + (row - 30)) * T1
+                    : row < 39 ? out.ee_vel + ((size_t)inst * 6 + (row - 33)) * T1
+                               : out.errors + ((size_t)inst * 7 + (row - 39)) * T1;
+        dst[cc] = sm.logbuf[row][e & (SLOGB - 1)];
+    }
+    fence();
+}
+
+SE_PASS int log_state(const Outputs &out, int inst, int T1, int col, int log_lo)
+{
+    SSmem &sm = g_ssm;
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        double z[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) z[i] = sm.xhat[i];
+        plant_log(sm.rb, z, sm.logv);
+        task_errors(sm.P, sm.rb, sm.logv, sm.logv + 15, sm.logv + 36);
+    }
+    fence();
+    if (lane < LOG_ROWS) {
+        const double v = lane < 12 ? sm.xhat[lane]
+                       : lane < 18 ? sm.u0[lane - 12]
+                       : lane < 30 ? sm.logv[lane - 18]
+                       : lane < 33 ? sm.logv[12 + (lane - 30)]
+                       : lane < 39 ? sm.logv[15 + (lane - 33)]
+                                   : sm.logv[36 + (lane - 39)];
+        sm.logbuf[lane][col & (SLOGB - 1)] = v;
+    }
+    fence();
+    col = uni(col); log_lo = uni(log_lo);
+    if ((col & (SLOGB - 1)) == SLOGB - 1) { log_flush(out, inst, T1, log_lo, col); log_lo = col + 1; }
+    return log_lo;
+}
+
+// Simulator.run (simulator.py:199-241) for steps [step0, step1) of one simulation, SQP_RTI.
+template <class FT>
+SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rbp, double *ws_base, size_t ws_stride,
+                    const Outputs &out, int inst, int step0, int step1)
+{
+    SSmem &sm = g_ssm;
+    const int lane = threadIdx.x;
+    const int N = pb.N, Nsim = pb.Nsim, T1 = Nsim + 1;
+    {
+        const double *ps = reinterpret_cast<const double *>(params + inst);
+        double *pd = reinterpret_cast<double *>(&sm.P);
+        for (int e = lane; e < (int)(sizeof(InstParams) / sizeof(double)); e += WAVE) pd[e] = ps[e];
+        const double *rs = reinterpret_cast<const double *>(rbp);
+        double *rd = reinterpret_cast<double *>(&sm.rb);
+        for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) rd[e] = rs[e];
+        if (lane == 0) { sm.w = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N); sm.n_hor = N; }
+    }
+    fence();
+    const InstParams &P = sm.P;
+    const SWs w = sm.w;
+    const size_t sbase = (size_t)inst * Nsim;
+    bool lin_valid = false;
+    double lin_cost = 0.0;
+    int log_lo = step0 == 0 ? 0 : step0 + 1;
+    if (step0 == 0) {
+        // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0
+        const size_t tot = sws_doubles_per_instance<FT>(N);
+        for (size_t e = lane; e < tot; e += WAVE) w.G1[e] = 0.0;      // G1 is the workspace base
+        fence();
+        for (int e = lane; e < (N + 1) * NX; e += WAVE) {
+            const int k = e / NX, i = e - k * NX;
+            w.G1[(size_t)k * W1 + O_X + i] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
+        }
+        if (lane < NX) sm.xhat[lane] = lane < 6 ? P.q0[lane] : P.qdot0[lane - 6];
+        if (lane < NU) sm.u0[lane] = P.qdot0[lane];                   // u[:,0] = qdot_0 (simulator.py:81)
+        __builtin_amdgcn_s_waitcnt(0);                                // the initial iterate is in memory before the first pass reads it
+        fence();
+        log_lo = uni(log_state(out, inst, T1, 0, log_lo));
+    } else {
+        if (lane < NX) sm.xhat[lane] = w.state[lane];
+        lin_cost = unid(w.state[12]);
+        lin_valid = uni(w.state[25] != 0.0 ? 1 : 0) != 0;
+        fence();
+    }
+    for (int i = step0; i < step1; i++) {
+        int qp_iter = 0, status = 0;
+        double res4[4] = {0, 0, 0, 0};
+        const double t0 = wclock();
+        // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
+        if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass(nullptr)); }
+        const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter);
+#ifdef MPCB_SPROF
+        if (lane == 0) { w.state[32 + 5] += wclock() - t0; }
+#endif
+        const bool ok = qs == 0 || qs == 1;
+        if (!ok) status = 4;                                           // ACADOS_QP_FAILURE, iterate untouched
+        __builtin_amdgcn_s_waitcnt(0);
+        lin_pass(1.0, ok);
+        __builtin_amdgcn_s_waitcnt(0);                                 // the records written lane by lane are complete before they are streamed
+        fence();
+        const double cost = unid(nlp_res_pass(res4));
+        lin_valid = true;
+        lin_cost = cost;
+        __builtin_amdgcn_s_waitcnt(0);
+        fence();
+        const double t1 = wclock();
+#ifdef MPCB_SPROF
+        if (lane == 0) { w.state[32 + 6] += t1 - t0; }
+#endif
+        // u = solver.get(0,'u'); plant step (simulation_model.py:93-117)
+        if (lane < 6) {
+            const int j = lane;
+            const double u = w.G1[O_U + j], wc = P.wcv[j], dt = P.dt;
+            const double q = sm.xhat[j], v = sm.xhat[6 + j];
+            const int integ = (int)P.integ;
+            const double k1q = v, k1v = -wc * v + wc * u;
+            const double v2 = v + 0.5 * dt * k1v;
+            const double k2q = v2, k2v = -wc * v2 + wc * u;
+            double qn, vn;
+            if (integ == 1) {
+                qn = q + dt * k1q; vn = v + dt * k1v;
+            } else if (integ == 2) {
+                qn = q + dt * k2q; vn = v + dt * k2v;
+            } else if (integ == 3) {
+                const double v3 = v - dt * k1v + 2.0 * dt * k2v;
+                const double k3q = v3, k3v = -wc * v3 + wc * u;
+                qn = q + (dt / 6) * (k1q + 4.0 * k2q + k3q); vn = v + (dt / 6) * (k1v + 4.0 * k2v + k3v);
+            } else {
+                const double v3 = v + 0.5 * dt * k2v;
+                const double k3q = v3, k3v = -wc * v3 + wc * u;
+                const double v4 = v + dt * k3v;
+                const double k4q = v4, k4v = -wc * v4 + wc * u;
+                qn = q + (dt / 6) * k1q + (dt / 3) * k2q + (dt / 3) * k3q + (dt / 6) * k4q;
+                vn = v + (dt / 6) * k1v + (dt / 3) * k2v + (dt / 3) * k3v + (dt / 6) * k4v;
+            }
+            sm.logv[24 + j] = qn;
+            sm.logv[30 + j] = vn;
+            sm.u0[j] = u;
+        }
+        if (lane == 8) {
+            out.status[sbase + i] = status;
+            out.sqp_iter[sbase + i] = 1;
+            out.qp_iter[sbase + i] = qp_iter;
+            out.cost[sbase + i] = cost;
+            out.solver_time[sbase + i] = t1 - t0;
+        }
+        if (lane >= 12 && lane < 16) out.residuals[(sbase + i) * 4 + (lane - 12)] =
+            lane == 12 ? res4[0] : (lane == 13 ? res4[1] : (lane == 14 ? res4[2] : res4[3]));
+        fence();
+        if (lane < NX) sm.xhat[lane] = sm.logv[24 + lane];
+        fence();
+        log_lo = uni(log_state(out, inst, T1, i + 1, log_lo));
+        const double t2 = wclock();
+        if (lane == 0) out.plant_time[sbase + i] = t2 - t1;
+    }
+    if (log_lo <= step1) log_flush(out, inst, T1, log_lo, step1);
+    if (lane < NX) w.state[lane] = sm.xhat[lane];
+    if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+}  // namespace se
+}  // namespace mpcb

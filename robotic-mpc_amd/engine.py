@@ -43,7 +43,7 @@ SUMMARY_COLS = ("rmse_e1", "rmse_e2", "rmse_e3", "rmse_e4", "rmse_e5", "itse_e1"
 
 class MpcbProblem(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("batch", "N", "Nsim", "solver_type", "max_iter", "qp_iter_max", "fixed_step",
-                                       "reserved")]
+                                       "precision")]
 
 
 class MpcbResult(C.Structure):
@@ -58,7 +58,7 @@ class EngineError(RuntimeError):
 
 _EXPORTS = ("mpcb_version", "mpcb_device_count", "mpcb_create", "mpcb_destroy", "mpcb_last_error",
             "mpcb_workspace_bytes", "mpcb_result_bytes_per_sim", "mpcb_setup", "mpcb_rollout", "mpcb_sync",
-            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_summary", "mpcb_run")
+            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_engine", "mpcb_summary", "mpcb_run")
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -96,6 +96,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.mpcb_run.argtypes = [C.c_void_p, C.POINTER(MpcbProblem), _dp, _dp, C.POINTER(MpcbResult)]
     lib.mpcb_summary.argtypes = [C.c_void_p, C.POINTER(MpcbResult), _dp, C.c_void_p]
     lib.mpcb_launch_info.argtypes = [C.c_void_p, _ip, _ip]
+    lib.mpcb_engine.argtypes = [C.c_void_p]
     if hasattr(lib, "mpcb_debug_task_lin"):
         lib.mpcb_debug_task_lin.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
     return lib
@@ -108,7 +109,7 @@ def make_problem(cfgs: Sequence[Dict]) -> MpcbProblem:
         if packing.bucket_key(c) != key0:
             raise ValueError("all simulations of one launch must share N, Nsim, solver options and robot")
     return MpcbProblem(len(cfgs), c0["N"], c0["Nsim"], c0["solver_type"], c0["max_iter"], c0["qp_iter_max"],
-                       int(c0["fixed_step"]), 0)
+                       int(c0["fixed_step"]), int(c0.get("precision", 0)))
 
 
 class MpcBatchEngine:
@@ -149,10 +150,11 @@ class MpcBatchEngine:
         return dict(vgprs=v[0].value, sgprs=v[1].value, lds_bytes=v[2].value, scratch_bytes=v[3].value)
 
     def launch_info(self) -> Dict[str, int]:
-        """Launch geometry chosen by setup(): wavefronts per simulation, LDS chunk pool bytes."""
+        """Launch geometry chosen by setup(): kernel family (0 latency, 1 throughput engine), wavefronts per
+        simulation, LDS chunk pool bytes."""
         w, pbytes = C.c_int(0), C.c_int(0)
         self._check(self.lib.mpcb_launch_info(self._h, C.byref(w), C.byref(pbytes)), "mpcb_launch_info")
-        return dict(waves_per_sim=w.value, pool_bytes=pbytes.value)
+        return dict(waves_per_sim=w.value, pool_bytes=pbytes.value, engine=int(self.lib.mpcb_engine(self._h)))
 
     # ------------------------------------------------------------------ device-resident path
     def setup(self, cfgs: Sequence[Dict], chain) -> MpcbProblem:

@@ -29,4 +29,5 @@ def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
 def bucket_key(cfg: Dict):
     """Instances that can share one launch: same horizon/steps/solver options and robot."""
     return (cfg["robot_name"], cfg.get("urdf_path"), cfg.get("ee_frame"), tuple(np.asarray(cfg["t_ee"]).tolist()),
-            cfg["N"], cfg["Nsim"], cfg["solver_type"], cfg["max_iter"], cfg["qp_iter_max"], bool(cfg["fixed_step"]))
+            cfg["N"], cfg["Nsim"], cfg["solver_type"], cfg["max_iter"], cfg["qp_iter_max"], bool(cfg["fixed_step"]),
+            int(cfg.get("precision", 0)))

@@ -1,0 +1,21 @@
+"""Per-pass device time of the throughput engine (diagnostic build -DMPCB_SPROF)."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["MPCB_ENGINE"] = "stream"
+import numpy as np
+import bench
+from robotic_mpc_amd import engine, robots
+ch = robots.builtin_chain("ur10")
+eng = engine.MpcBatchEngine(0, lib_path=os.path.join(ROOT, "robotic-mpc_amd", os.environ.get("SPROF_LIB", "libmpcbatch_sprof.so")))
+for B in [int(v) for v in sys.argv[1:]] or [1024, 2048]:
+    cfgs = bench.workload_configs(B, 100, 0.5, seed=1, solver="SQP_RTI")
+    pb, bufs = eng.run_device(cfgs, ch)
+    ms = sum(eng.last_kernel_ms)
+    out = np.zeros(16)
+    eng.lib.mpcb_debug_profile(eng._h, B // 2, out.ctypes.data_as(C.POINTER(C.c_double)))
+    it = out[7]
+    names = ["fact", "fwd_aff", "corr", "fwd", "resid", "ipm_total", "nlp_step_total"]
+    print(f"B={B}: kernel {ms:.1f} ms for {pb.Nsim} steps; sim {B//2}: {it:.0f} IPM iterations; per IPM iteration and stage (us): " +
+          ", ".join(f"{n} {out[i]/it/101*1e6:.2f}" for i, n in enumerate(names[:5])) +
+          f"; per step: ipm {out[5]/pb.Nsim*1e6:.0f} us, nlp_step {out[6]/pb.Nsim*1e6:.0f} us", flush=True)

@@ -1,0 +1,150 @@
+"""The THROUGHPUT engine (csrc/mpc_stream.h: one wavefront per simulation, stage records streamed through LDS) and
+its fp32-Riccati leg (BASELINE.json configs[4]) through the C ABI, against the CPU oracle.
+
+fp64: q, qdot, u, poses within 1e-9 of the oracle, status and iteration counts identical (same bar as the latency
+engine).  fp32 Riccati (factor K, P, R~^-1, p and the three solve sweeps in fp32; iterate, residuals, steps fp64):
+the interior point still converges to qp_tol = 1e-8 in fp64 residuals, so the closed loop stays within FP32_BOUND of
+the fp64 run; statuses agree, iteration counts may differ by a few.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+ATOL = 1e-9
+FP32_BOUND = 5e-6      # max |fp32 - fp64| on q, qdot, u over >= 100 closed-loop steps at N = 300 (measured 2e-7 .. 1e-6)
+
+
+@pytest.fixture()
+def stream_engine(monkeypatch):
+    from robotic_mpc_amd import engine
+
+    monkeypatch.setenv("MPCB_ENGINE", "stream")
+    e = engine.MpcBatchEngine(0)
+    yield e
+    e.close()
+
+
+def _cfg(**kw):
+    from robotic_mpc_amd import config
+
+    return config.resolve_config(config.base_params(**kw))
+
+
+def _jitter(n, seed=0, **kw):
+    from robotic_mpc_amd import config
+
+    rng = np.random.default_rng(seed)
+    return [_cfg(q_0=config.BASE_PARAMS["q_0"] + rng.uniform(-0.1, 0.1, 6), **kw) for _ in range(n)]
+
+
+def _check(out, i, ref, atol=ATOL):
+    for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):
+        np.testing.assert_allclose(out[k][i], ref[k], atol=atol, rtol=0, err_msg=k)
+    np.testing.assert_allclose(out["cost"][i], ref["cost"], atol=1e-9, rtol=1e-9)
+    np.testing.assert_allclose(out["residuals"][i], ref["residuals"], atol=1e-7)
+    for k in ("status", "sqp_iter", "qp_iter"):
+        np.testing.assert_array_equal(out[k][i], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize("N,T,B", [(20, 1.0, 4), (100, 0.3, 2), (1, 0.1, 1), (2, 0.1, 2), (3, 0.05, 1), (7, 0.2, 3), (130, 0.05, 2),
+                                   (300, 0.03, 1)])
+def test_stream_engine_matches_oracle(stream_engine, orc, ur10, ur10_rb, N, T, B):
+    cfgs = _jitter(B, seed=N, prediction_horizon=N, simulation_time=T)
+    out = stream_engine.run(cfgs, ur10)
+    assert stream_engine.launch_info()["engine"] == 1
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+
+
+def test_stream_engine_bounds_parameters_integrators_lm(stream_engine, orc, ur10, ur10_rb):
+    cfgs = [
+        _cfg(prediction_horizon=15, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
+             qdot_0=np.array([0.5, 0.7, 0.5, 0, 0, 0.0])),
+        _cfg(prediction_horizon=15, simulation_time=0.3, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
+             w_qddot=0.05, px_ref=0.5, vy_ref=-0.02, surface_coeffs=dict(a=-0.1, b=0.12, c=0.0, d=0.02, e=-0.01, f=0.05)),
+        _cfg(prediction_horizon=15, simulation_time=0.3, q_min=np.full(6, -1e30), q_max=np.full(6, 1e30)),   # absent bounds
+        _cfg(prediction_horizon=15, simulation_time=0.3, integration_method="RK2"),
+        _cfg(prediction_horizon=15, simulation_time=0.3, solver_options={"nlp_solver_type": "SQP_RTI", "levenberg_marquardt": 0.3}),
+    ]
+    out = stream_engine.run(cfgs, ur10)
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+    assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6
+
+
+def test_stream_engine_chunked_launches_and_errors_match(stream_engine, ur10):
+    from robotic_mpc_amd import analysis
+
+    cfgs = _jitter(3, seed=5, prediction_horizon=25, simulation_time=0.4)
+    a = stream_engine.run(cfgs, ur10)
+    b = stream_engine.run(cfgs, ur10, step_chunk=7)          # state carried across launches in the HBM workspace
+    for k in ("z", "u", "ee_pose", "cost", "residuals", "status", "qp_iter", "errors"):
+        assert np.array_equal(a[k], b[k]), k
+    for i, c in enumerate(cfgs):
+        e = analysis.compute_errors(a["ee_pose"][i], a["ee_vel"][i], c["coeffs"], c["t_ee"], c["px_ref"], c["vy_ref"])
+        np.testing.assert_allclose(a["errors"][i], analysis.errors_rows(e), atol=1e-12, rtol=0)
+
+
+def test_large_rti_batch_takes_the_stream_engine_and_matches_both(orc, ur10, ur10_rb, monkeypatch):
+    """Default selection (no environment override): an SQP_RTI batch of MPCB_STREAM_MIN_BATCH simulations runs on the
+    throughput engine; spot checks against the oracle and, bit for bit where it matters (status, iterations), against
+    the latency engine on the same simulations."""
+    from robotic_mpc_amd import engine
+
+    monkeypatch.delenv("MPCB_ENGINE", raising=False)
+    cfgs = _jitter(2048, seed=9, prediction_horizon=20, simulation_time=0.3)
+    e = engine.MpcBatchEngine(0)
+    try:
+        out = e.run(cfgs, ur10)
+        assert e.launch_info()["engine"] == 1
+        assert (out["status"] == 0).all() and np.isfinite(out["z"]).all()
+        for i in (0, 777, 2047):
+            _check(out, i, orc.run(ur10_rb, orc.make_params(cfgs[i])))
+        sub = [cfgs[i] for i in (0, 777, 2047)]
+        lat = e.run(sub, ur10)                                  # 3 simulations: the latency engine
+        assert e.launch_info()["engine"] == 0
+        for j, i in enumerate((0, 777, 2047)):
+            np.testing.assert_array_equal(lat["qp_iter"][j], out["qp_iter"][i])
+            np.testing.assert_allclose(lat["z"][j], out["z"][i], atol=1e-11, rtol=0)
+    finally:
+        e.close()
+
+
+def test_fp32_riccati_long_horizon_stays_close_to_fp64(ur10):
+    """BASELINE configs[4]: N = 300, SQP_RTI, Riccati in fp32 vs fp64 (both on the throughput engine): deviation of the
+    closed loop over 120 steps, status equality, iteration overhead."""
+    from robotic_mpc_amd import engine
+
+    e = engine.MpcBatchEngine(0)
+    try:
+        c64 = _jitter(8, seed=300, prediction_horizon=300, simulation_time=1.2)
+        c32 = _jitter(8, seed=300, prediction_horizon=300, simulation_time=1.2, riccati_precision="fp32")
+        os.environ["MPCB_ENGINE"] = "stream"
+        try:
+            a = e.run(c64, ur10)
+            assert e.launch_info()["engine"] == 1
+        finally:
+            del os.environ["MPCB_ENGINE"]
+        b = e.run(c32, ur10)                                     # precision = fp32 selects the throughput engine by itself
+        assert e.launch_info()["engine"] == 1
+        dev = max(float(np.abs(a[k] - b[k]).max()) for k in ("z", "u"))
+        print(f"configs[4] N=300, 120 steps, 8 sims: max |fp32 - fp64| on q, qdot, u = {dev:.3e}; "
+              f"IPM iterations fp64 {a['qp_iter'].sum()} fp32 {b['qp_iter'].sum()}; failures fp64 {(a['status'] != 0).sum()} fp32 {(b['status'] != 0).sum()}")
+        assert dev < FP32_BOUND
+        np.testing.assert_array_equal(a["status"], b["status"])
+        assert (a["status"] == 0).all()
+        assert b["qp_iter"].sum() <= 1.25 * a["qp_iter"].sum() + 20
+        assert dev > 0.0                                         # it really is another arithmetic
+    finally:
+        e.close()
+
+
+def test_fp32_riccati_rejected_for_full_sqp(ur10):
+    from robotic_mpc_amd import config
+
+    with pytest.raises(ValueError, match="SQP_RTI"):
+        config.resolve_config(config.base_params(riccati_precision="fp32", solver_options={"nlp_solver_type": "SQP"}))
