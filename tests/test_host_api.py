@@ -376,3 +376,21 @@ def test_reference_plotter_consumes_run_all_results(orc):
     assert len(fig.data) >= 2
     # the integration-time box is no longer empty
     assert (res[0]["simulator"].timings["integration_time"] > 0).all()
+
+
+def test_riccati_precision_is_a_bucket_property():
+    """BASELINE configs[4]: `riccati_precision` travels config -> bucket key -> mpcb_problem.precision."""
+    from robotic_mpc_amd import config, distributed, engine, packing
+
+    a = config.resolve_config(config.base_params())
+    b = config.resolve_config(config.base_params(riccati_precision="fp32"))
+    assert a["precision"] == 0 and b["precision"] == 1
+    assert packing.bucket_key(a) != packing.bucket_key(b)
+    assert len(distributed.group_buckets([a, b, a])) == 2
+    assert engine.make_problem([b]).precision == 1 and engine.make_problem([a, a]).precision == 0
+    with pytest.raises(ValueError):
+        engine.make_problem([a, b])
+    with pytest.raises(ValueError):
+        config.resolve_config(config.base_params(riccati_precision="fp16"))
+    with pytest.raises(ValueError, match="SQP_RTI"):
+        config.resolve_config(config.base_params(riccati_precision="fp32", solver_options={"nlp_solver_type": "SQP"}))
