@@ -43,10 +43,13 @@ constexpr int SRI = 196;   // R~^-1 (36)
 constexpr int SW4 = 232;
 constexpr int SW4_AFF = SPV, SW4_FWD = SWV;
 
+// One simulation's workspace: ONE record per stage, [G1 | G2 | G3 | G4] side by side (all the records a pass touches
+// of a stage sit in the same few KB: fewer DRAM pages open per pass than with one array per group), then the scalars.
 struct SWs {
-    double *G1, *G2, *G3;
-    char *G4;          // rows of SW4 scalars of the factor type
+    double *G1, *G2, *G3;   // row 0 of each group inside the stage record
+    char *G4;               // SW4 scalars of the factor type
     double *state;
+    int ld;                 // stage record stride (bytes)
 };
 template <class FT>
 MPC_HD size_t sws_doubles_per_instance(int N)
@@ -58,12 +61,12 @@ MPC_HD SWs sws_carve(double *base, int N)
 {
     const size_t n1 = (size_t)N + 1;
     SWs w;
-    double *p = base;
-    w.G1 = p; p += n1 * W1;
-    w.G2 = p; p += n1 * W2;
-    w.G3 = p; p += n1 * W3;
-    w.G4 = (char *)p; p += n1 * (SW4 * sizeof(FT) / 8);
-    w.state = p;
+    w.ld = (W1 + W2 + W3) * 8 + SW4 * (int)sizeof(FT);
+    w.G1 = base;
+    w.G2 = base + W1;
+    w.G3 = base + W1 + W2;
+    w.G4 = (char *)(base + W1 + W2 + W3);
+    w.state = base + n1 * (size_t)(w.ld / 8);
     return w;
 }
 
@@ -154,9 +157,9 @@ struct Seg {
     int ld;         // row stride (bytes)
     int off, w;     // byte range inside the row (multiples of 16)
 };
-SE_DEV Seg segd(double *base, int ld, int c0, int w) { Seg s; s.base = (char *)base; s.ld = ld * 8; s.off = c0 * 8; s.w = w * 8; return s; }
+SE_DEV Seg segd(double *base, int ld_bytes, int c0, int w) { Seg s; s.base = (char *)base; s.ld = ld_bytes; s.off = c0 * 8; s.w = w * 8; return s; }
 template <class FT>
-SE_DEV Seg segf(char *base, int c0, int w) { Seg s; s.base = base; s.ld = SW4 * (int)sizeof(FT); s.off = c0 * (int)sizeof(FT); s.w = w * (int)sizeof(FT); return s; }
+SE_DEV Seg segf(char *base, int ld_bytes, int c0, int w) { Seg s; s.base = base; s.ld = ld_bytes; s.off = c0 * (int)sizeof(FT); s.w = w * (int)sizeof(FT); return s; }
 
 template <int NI>
 struct Bundle {
@@ -225,25 +228,28 @@ struct Ring {
     int slot_doubles, slots;
     SE_DEV double *row(int k) const { return g_ssm.ring + (k % slots) * slot_doubles; }
 };
-template <int NI>
+// ITEMS = 16-byte items of the bundle: a slot is exactly that long (the last copy instruction of a row is
+// exec-masked beyond its items, so nothing spills into the next slot)
+template <int ITEMS>
 SE_DEV Ring make_ring()
 {
     Ring rg;
-    rg.slot_doubles = NI * 2 * WAVE;
+    rg.slot_doubles = ITEMS * 2;
     rg.slots = RING_DOUBLES / rg.slot_doubles > 12 ? 12 : RING_DOUBLES / rg.slot_doubles;
     return rg;
 }
-template <int NI, int NO, bool BACK, class F>
+template <int ITEMS, int NO, bool BACK, int NI, class F>
 SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
 {
-    constexpr int SLOT = NI * 2 * WAVE;                      // doubles (whole copy pieces)
+    static_assert((ITEMS + WAVE - 1) / WAVE == NI, "bundle size and copy instruction count disagree");
+    constexpr int SLOT = ITEMS * 2;                          // doubles
     constexpr int SLOTS = RING_DOUBLES / SLOT > 12 ? 12 : RING_DOUBLES / SLOT;
     constexpr int D = SLOTS - 2;
     static_assert(D >= 1, "ring too small for this bundle");
     // issue order per stage: [wait] compute, stores of row i, fetch of row i+1+D
     constexpr int W_STEADY = (D - 1) * (NI + NO), W_EARLY = (D - 1) * NI, W_LATE = (D - 1) * NO;
     static_assert(W_STEADY < 64, "vmcnt range");
-    const Ring rg = make_ring<NI>();
+    const Ring rg = make_ring<ITEMS>();
     auto row = [&](int i) { return BACK ? N - i : i; };
     (void)lane;
     wait_vm<0>();                                            // nothing of an earlier pass is in flight
@@ -327,24 +333,36 @@ SE_PASS IpmNorms residual_pass(double a)
     constexpr int O_W = 0, O_RY = 78, O_G = 88, O_3 = 130;   // output image
     Bundle<2> bin, bout;
     {
-        const Seg si[3] = {segd(w.G1, W1, 0, W1), segd(w.G3, W3, O_DW, 78), segd(w.G2, W2, 0, W2_LIN)};
+        const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G3, w.ld, O_DW, 78), segd(w.G2, w.ld, 0, W2_LIN)};
         bin.setup(si, lane);
-        const Seg so[4] = {segd(w.G1, W1, O_QW, 78), segd(w.G2, W2, 0, 10), segd(w.G2, W2, O_GAM, 42), segd(w.G3, W3, 0, 66)};
+        const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, 10), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)};
         bout.setup(so, lane);
     }
     double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0, ncl = 0;
+    // Everything a lane needs of the parameters sits in its registers for the whole sweep (LDS reads of the parameter
+    // block inside the stage loop also make the compiler drain the fetches in flight: same LDS object as the ring).
+    const int lj = lane >= 18 && lane < 30 ? lane - 18 : 0;                 // lanes 18..29: bounded component (update) / row of rb
+    const bool lj_lo = bnd_lo(P, lj) > -BOUND_INF, lj_hi = bnd_hi(P, lj) < BOUND_INF;
+    const int ci = lane < NW ? lane : 0, cls = ci / 6, cj = ci - cls * 6;     // lanes 0..17: stationarity row
+    const bool c_lo = cls < 2 && bnd_lo(P, ci < NB ? ci : 0) > -BOUND_INF, c_hi = cls < 2 && bnd_hi(P, ci < NB ? ci : 0) < BOUND_INF;
+    const double cb_lo = bnd_lo(P, ci < NB ? ci : 0), cb_hi = bnd_hi(P, ci < NB ? ci : 0);
+    const double k_dt = P.dt, k_2wu = 2.0 * P.w_u, k_c2 = P.w_qddot * P.cq[cj] * P.cq[cj], k_lm = P.lm;
+    const double k_p1 = cls == 0 ? P.b1[cj] : P.a12[cj], k_p2 = cls == 0 ? P.b2[cj] : P.a22[cj];
+    const double k_wt = P.w_task[lane < NTASK ? lane : 0];
+    const double k_ra = lj < 6 ? P.a12[lj] : P.a22[lj - 6], k_rb = lj < 6 ? P.b1[lj] : P.b2[lj - 6];
+    const double xh = lane < NX ? sm.xhat[lane] : 0.0;
     // update of one landed row: dw += a ddw ; (lam, t) += a (dlam, dt) -- or the warm-start clamp in mode 0
     auto upd_row = [&](double *row, int kr) {
         if (MODE == 1) {
             if (lane < NW) row[O_QW + lane] += a * row[I_D + lane];
         } else {
-            if (kr == 0 && lane < NX) row[O_QW + 6 + lane] = sm.xhat[lane] - row[O_X + lane];
+            if (kr == 0 && lane < NX) row[O_QW + 6 + lane] = xh - row[O_X + lane];
             if (kr == N && lane >= 12 && lane < 18) row[O_QW + lane - 12] = 0.0;
         }
         if (lane >= 18 && lane < 30) {
-            const int j = lane - 18;
-            const bool hc = has_comp(N, kr, j);
-            const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+            const int j = lj;
+            const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
+            const bool blo = hc && lj_lo, bhi = hc && lj_hi;
             double *lam = row + O_QLAM, *t = row + O_QT;
             if (MODE == 0) {
                 if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
@@ -362,9 +380,12 @@ SE_PASS IpmNorms residual_pass(double a)
         }
     };
     if (lane < NX) sm.vec[0][lane] = 0.0;      // pi_{-1}: never read (k = 0 rows return early)
-    sweep<2, 2, false>(bin, N, lane, [&](int k, const Ring &rg) {
+    sweep<117, 2, false>(bin, N, lane, [&](int k, const Ring &rg) {
         double *cur = rg.row(k), *nxt = rg.row(k + 1);
         double *o = sm.out[k & 1];
+#ifdef MPCB_NOCOMPUTE
+        (void)cur; (void)nxt; store_out(bout, k, o, lane); return;
+#endif
         if (k == 0) upd_row(cur, 0);
         // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
         if (k + 1 <= N) {
@@ -382,28 +403,56 @@ SE_PASS IpmNorms residual_pass(double a)
 #pragma unroll
                 for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
             }
-            cur[I_L + O_Y + lane] = P.w_task[lane] * v;
+            cur[I_L + O_Y + lane] = k_wt * v;
         }
         fence();
-        // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29), copies (lanes 32..)
+        // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29)
         {
             const double *r1 = cur, *r2 = cur + I_L;
             const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
             if (lane < NW) {
-                const int cls = lane / 6, j = lane - cls * 6, ci = lane;
-                double rg = cls == 0 ? stat_cls<0>(N, k, j, r1, r2, true, pk, pm)
-                          : cls == 1 ? stat_cls<1>(N, k, j, r1, r2, true, pk, pm) : stat_cls<2>(N, k, j, r1, r2, true, pk, pm);
+                const int j = cj;
+                // stationarity of the QP at w + dw (mpc_core.h stat_cls with `with_delta`), same operation order
+                double rg = 0.0;
+                if (cls == 0) {
+                    if (k < N) {
+                        const double uj = r1[O_U + j] + r1[O_QW + j], vj = r1[O_X + 6 + j] + r1[O_QW + 12 + j];
+                        rg = k_dt * (k_2wu * uj + k_c2 * (uj - vj));
+                        rg += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                        rg += k_dt * k_lm * r1[O_QW + j];
+                    }
+                } else if (cls == 1) {
+                    if (k > 0) {
+                        if (k < N) {
+                            double s = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
+                            rg = k_dt * s + pk[j];
+                        }
+                        rg += (k < N ? k_dt : 1.0) * k_lm * r1[O_QW + 6 + j];
+                        rg -= pm[j];
+                    }
+                } else {
+                    if (k > 0) {
+                        if (k < N) {
+                            const double uj = r1[O_U + j] + r1[O_QW + j], vj = r1[O_X + 6 + j] + r1[O_QW + 12 + j];
+                            rg = k_dt * (r2[O_GV + j] * r2[O_Y + 4] + k_c2 * (vj - uj));
+                            rg += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                        }
+                        rg += (k < N ? k_dt : 1.0) * k_lm * r1[O_QW + 12 + j];
+                        rg -= pm[6 + j];
+                    }
+                }
                 double gt = rg;
                 if (cls < 2) {
-                    const bool hc = has_comp(N, k, ci);
-                    const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                    const bool hc = cls == 0 ? k < N : (k >= 1 && k < N);
+                    const bool blo = hc && c_lo, bhi = hc && c_hi;
                     const double v_ = r1[cls == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
                     double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
                     const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
-                    const double b_lo = bnd_lo(P, ci), b_hi = bnd_hi(P, ci);
                     if (blo) {
                         const double l = l_lo, t = t_lo, it = fast_rcp(t);
-                        rdl = dv - (b_lo - v) - t;
+                        rdl = dv - (cb_lo - v) - t;
                         rml = l * t;
                         rg -= l; gt -= l;
                         gam += l * it;
@@ -413,7 +462,7 @@ SE_PASS IpmNorms residual_pass(double a)
                     }
                     if (bhi) {
                         const double l = l_hi, t = t_hi, it = fast_rcp(t);
-                        rdu = (b_hi - v) - dv - t;
+                        rdu = (cb_hi - v) - dv - t;
                         rmu = l * t;
                         rg += l; gt += l;
                         gam += l * it;
@@ -429,12 +478,12 @@ SE_PASS IpmNorms residual_pass(double a)
                 o[O_G + 12 + ci] = gt;
                 a_g = fmax(a_g, fabs(rg));
             } else if (lane < 30) {
-                const int i = lane - 18;
+                const int i = lj;
                 double v = 0.0;
                 if (k < N) {
                     const double *dw = cur + O_QW, *dn = nxt + O_QW;
-                    if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
-                    else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
+                    if (i < 6) v = dw[6 + i] + k_ra * dw[12 + i] + k_rb * dw[i];
+                    else v = k_ra * dw[6 + i] + k_rb * dw[i - 6];
                     v += r2[O_BD + i] - dn[6 + i];
                     a_b = fmax(a_b, fabs(v));
                 }
@@ -481,9 +530,9 @@ SE_PASS void fact_pass()
     Bundle<1> bin;
     Bundle<NIO> bout;
     {
-        const Seg si[1] = {segd(w.G2, W2, O_GQ, 78)};
+        const Seg si[1] = {segd(w.G2, w.ld, O_GQ, 78)};
         bin.setup(si, lane);
-        const Seg so[1] = {segf<FT>(w.G4, 0, SW4)};
+        const Seg so[1] = {segf<FT>(w.G4, w.ld, 0, SW4)};
         bout.setup(so, lane);
     }
     FactLane<FT> f;
@@ -509,6 +558,7 @@ SE_PASS void fact_pass()
 #pragma unroll
     for (int i = 0; i < 6; i++) { b1r[i] = (FT)P.b1[i]; b2r[i] = (FT)P.b2[i]; }
     FT pr = (FT)0;                                                // vector lanes: p_{k+1}[jv]
+    const FT lmN = (FT)P.lm;
     int sb = 0;
     auto next_stage = [&](FT gam_u, int sbw) {
         const FT fq = f.b1a * f.mqq + f.b2a * f.mvq, fv = f.b1a * f.mqv + f.b2a * f.mvv;
@@ -524,15 +574,17 @@ SE_PASS void fact_pass()
         f.qvq = cq;
         f.qvv = cq * f.a12b + cv * f.a22b;
     };
-    sweep<1, NIO, true>(bin, N, lane, [&](int k, const Ring &rg) {
+    sweep<39, NIO, true>(bin, N, lane, [&](int k, const Ring &rg) {
         const double *ric = rg.row(k);
         const double *ricd = rg.row(k > 0 ? k - 1 : 0);           // row k-1 (valid for k >= 1)
         MPC_LOCAL FT *fac = (MPC_LOCAL FT *)sm.out[k & 1];
         const MPC_LOCAL FT *facn = (const MPC_LOCAL FT *)sm.out[(k + 1) & 1];   // row k+1 (valid for k < N)
+#ifdef MPCB_NOCOMPUTE
+        (void)ric; (void)ricd; (void)fac; (void)facn; store_out(bout, k, sm.out[k & 1], lane); return;
+#endif
         const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
         if (k == N) {
             // terminal stage: no cost, no bounds -> P_N = lm I ; p_N = gt_x ; R~, S~ of stage N-1
-            const FT lmN = (FT)P.lm;
             for (int e = lane; e < SW4; e += WAVE) fac[e] = (FT)0;
             fence();
             if (lane < NX) fac[SPM + tri(lane, lane)] = lmN;
@@ -690,25 +742,31 @@ SE_PASS StepInfo forward_pass()
     const SWs w = sm.w;
     constexpr int LF = AFFINE ? SW4_AFF : SW4_FWD;
     constexpr int FB = LF * (int)sizeof(FT);                       // bytes of the factor part
+    constexpr int ITEMS = (FB + 96 * 8) / 16;
     constexpr int NII = ni_of(FB + 96 * 8);
     constexpr int I_LT = FB / 8, I_R = I_LT + 48;                  // doubles
     Bundle<NII> bin;
     Bundle<1> bout;
     {
-        const Seg si[3] = {segf<FT>(w.G4, 0, LF), segd(w.G1, W1, O_QLAM, 48), segd(w.G3, W3, O_RD, 48)};
+        const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)};
         bin.setup(si, lane);
-        if (AFFINE) { const Seg so[1] = {segd(w.G3, W3, O_DLAM, 48)}; bout.setup(so, lane); }
-        else { const Seg so[1] = {segd(w.G3, W3, O_DW, 78)}; bout.setup(so, lane); }
+        if (AFFINE) { const Seg so[1] = {segd(w.G3, w.ld, O_DLAM, 48)}; bout.setup(so, lane); }
+        else { const Seg so[1] = {segd(w.G3, w.ld, O_DW, 78)}; bout.setup(so, lane); }
     }
     const int j12 = lane & 15;                                     // component of the 12-lane roles
     const int j6 = j12 % 6;
     const FT a12 = (FT)P.a12[j6], a22 = (FT)P.a22[j6], b1 = (FT)P.b1[j6], b2 = (FT)P.b2[j6];
     double al = 1.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int jl = lane >= 48 && lane < 60 ? lane - 48 : 0;        // lagging role: bounded component
+    const bool jl_lo = bnd_lo(P, jl) > -BOUND_INF, jl_hi = bnd_hi(P, jl) < BOUND_INF;
     if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
     auto stage = [&](int k, const Ring &rg) {
         const double *row = rg.row(k), *rowp = rg.row(k > 0 ? k - 1 : 0);
         const MPC_LOCAL FT *fac = (const MPC_LOCAL FT *)row;
         double *o = sm.out[k & 1], *op = sm.out[(k + 1) & 1];
+#ifdef MPCB_NOCOMPUTE
+        (void)row; (void)rowp; (void)fac; (void)o; if (k >= 1) store_out(bout, k - 1, AFFINE ? op + 30 : op, lane); return;
+#endif
         const double *dxk = sm.vec[k & 1];
         if (lane < 12 && k <= N) {
             const int i = lane < 6 ? lane : lane - 6;
@@ -740,11 +798,11 @@ SE_PASS StepInfo forward_pass()
             }
             o[18 + j] = v;                                          // DPI slot of stage k holds dpi_{k-1}
         } else if (lane >= 48 && lane < 60 && k >= 1) {
-            const int j = lane - 48, kp = k - 1;
+            const int j = jl, kp = k - 1;
             const double *lt = rowp + I_LT, *r = rowp + I_R;
             const double dv = j < 6 ? op[j] : op[6 + (j - 6)];       // du_{k-1}[j] or dq_{k-1}[j-6]
-            const bool hc = has_comp(N, kp, j);
-            const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+            const bool hc = j < 6 ? kp < N : (kp >= 1 && kp < N);
+            const bool blo = hc && jl_lo, bhi = hc && jl_hi;
             const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
             const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
             double dtl = 0, dll = 0, dtu = 0, dlu = 0;
@@ -768,9 +826,9 @@ SE_PASS StepInfo forward_pass()
         fence();
         if (k >= 1) store_out(bout, k - 1, AFFINE ? op + 30 : op, lane);
     };
-    sweep<NII, 1, false>(bin, N, lane, stage);
+    sweep<ITEMS, 1, false>(bin, N, lane, stage);
     fence();
-    stage(N + 1, make_ring<NII>());      // the lagging role's last stage
+    stage(N + 1, make_ring<ITEMS>());      // the lagging role's last stage
     StepInfo s;
     s.alpha = wmin(al); s.S0 = wsum(a0); s.S1 = wsum(a1); s.S2 = wsum(a2);
     return s;
@@ -792,26 +850,32 @@ SE_PASS void corrector_pass(double sigma_mu)
     const SWs w = sm.w;
     constexpr int I_3 = 48, I_DL = 90, I_GB = 138, I_F = 168;      // doubles: lam,t | RG,RD | DLAM,DT | GT,RB | factor parts
     constexpr int FBYTES = (72 + 48) * (int)sizeof(FT);
+    constexpr int ITEMS = (168 * 8 + FBYTES) / 16;
     constexpr int NII = ni_of(168 * 8 + FBYTES);
     constexpr int OB = 24 * 8 + 32 * (int)sizeof(FT);
     Bundle<NII> bin;
     Bundle<1> bout;
     {
-        const Seg si[6] = {segd(w.G1, W1, O_QLAM, 48), segd(w.G3, W3, 0, 42), segd(w.G3, W3, O_DLAM, 48), segd(w.G2, W2, O_GT, 30),
-                           segf<FT>(w.G4, SK, 72), segf<FT>(w.G4, SWV, 48)};
+        const Seg si[6] = {segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, 0, 42), segd(w.G3, w.ld, O_DLAM, 48), segd(w.G2, w.ld, O_GT, 30),
+                           segf<FT>(w.G4, w.ld, SK, 72), segf<FT>(w.G4, w.ld, SWV, 48)};
         bin.setup(si, lane);
-        const Seg so[2] = {segd(w.G3, W3, O_RM, 24), segf<FT>(w.G4, SVH, 32)};
+        const Seg so[2] = {segd(w.G3, w.ld, O_RM, 24), segf<FT>(w.G4, w.ld, SVH, 32)};
         bout.setup(so, lane);
         (void)OB;
     }
     const int j12 = lane & 15, j6 = j12 % 6;
     const FT va12 = (FT)P.a12[j6], va22 = (FT)P.a22[j6];
+    const FT hb1 = (FT)P.b1[lane < 6 ? lane : 0], hb2 = (FT)P.b2[lane < 6 ? lane : 0];       // h_u lanes
+    const int je = lane >= 16 && lane < 28 ? lane - 16 : 0;
+    const FT eb = (FT)(je < 6 ? P.b1[je] : P.b2[je - 6]);                                   // e lanes: row of B
+    const int jc = lane >= 32 && lane < 44 ? lane - 32 : 0;
+    const bool jc_lo = bnd_lo(P, jc) > -BOUND_INF, jc_hi = bnd_hi(P, jc) < BOUND_INF;      // corrector lanes
     // corrector of one landed row -> sm.gtc[kr & 1] (18 entries) and the RM slot of that row's output image
     auto corr_row = [&](const double *row, int kr, int j) {
         const double *lt = row, *r3 = row + I_3, *dl = row + I_DL, *gtb = row + I_GB;
         double *og = sm.gtc[kr & 1], *rmo = sm.out[kr & 1];
-        const bool hc = has_comp(N, kr, j);
-        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+        const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
+        const bool blo = hc && jc_lo, bhi = hc && jc_hi;
         const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
         const double dll = dl[j], dtl = dl[24 + j], dlu = dl[12 + j], dtu = dl[36 + j];
         const double rdl = r3[18 + j], rdu = r3[18 + 12 + j];
@@ -824,12 +888,15 @@ SE_PASS void corrector_pass(double sigma_mu)
         if (j < 6) og[12 + j] = gtb[12 + j];
         rmo[j] = rml; rmo[12 + j] = rmu;
     };
-    sweep<NII, 1, true>(bin, N, lane, [&](int k, const Ring &rg) {
+    sweep<ITEMS, 1, true>(bin, N, lane, [&](int k, const Ring &rg) {
         const double *row = rg.row(k), *rowd = rg.row(k > 0 ? k - 1 : 0);
         if (k == N) {
             if (lane >= 32 && lane < 44) corr_row(row, N, lane - 32);
             fence();
         }
+#ifdef MPCB_NOCOMPUTE
+        (void)rowd; store_out(bout, k, sm.out[k & 1], lane); return;
+#endif
         const double *gtc = sm.gtc[k & 1], *gtb = row + I_GB;
         const MPC_LOCAL FT *kf = (const MPC_LOCAL FT *)(row + I_F), *wv = kf + 72, *ri = kf + 84;
         double *o = sm.out[k & 1];
@@ -838,7 +905,7 @@ SE_PASS void corrector_pass(double sigma_mu)
         // ---- X: h_u (lanes 0..5) ; corrector of row k-1 (lanes 32..43)
         if (lane < 6 && k < N) {
             const FT t0 = (FT)pn[lane] + wv[lane], t1 = (FT)pn[6 + lane] + wv[6 + lane];
-            sm.vec[2][lane] = (double)((FT)gtc[lane] + (FT)P.b1[lane] * t0 + (FT)P.b2[lane] * t1);
+            sm.vec[2][lane] = (double)((FT)gtc[lane] + hb1 * t0 + hb2 * t1);
         } else if (lane >= 32 && lane < 44 && k >= 1) {
             corr_row(rowd, k - 1, lane - 32);
         }
@@ -866,7 +933,7 @@ SE_PASS void corrector_pass(double sigma_mu)
 #pragma unroll
                 for (int m = 0; m < 6; m += 2) { v0 += ri[i6 * 6 + m] * (FT)sm.vec[2][m]; v1 += ri[i6 * 6 + m + 1] * (FT)sm.vec[2][m + 1]; }
                 vh = v0 + v1;
-                e = (FT)gtb[18 + j] - (FT)(j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
+                e = (FT)gtb[18 + j] - eb * vh;
             }
             if (j < 6) ofac[j] = vh;
             ofac[8 + j] = e;
@@ -905,6 +972,9 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out)
         else if (it >= qp_iter_max) stop = 1;
         else if (!(alpha > 1e-12)) stop = 2;
         stop = uni(stop);
+#ifdef MPCB_NOCOMPUTE
+        stop = it >= 3 ? 0 : -1;     // memory-only timing build: three iterations per QP, whatever the (meaningless) norms say
+#endif
         if (stop >= 0) { status = stop; break; }
         SPROF_T0(tf);
         fact_pass<FT>();
@@ -954,8 +1024,8 @@ SE_PASS void lin_pass(double alpha, bool do_update)
     for (int k0 = 0; k0 <= N; k0 += WAVE) {
         const int k = k0 + lane;
         if (k > N) continue;
-        MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)(w.G1 + (size_t)k * W1);
-        MPC_GLOBAL double *r2 = (MPC_GLOBAL double *)(w.G2 + (size_t)k * W2);
+        MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)k * w.ld);
+        MPC_GLOBAL double *r2 = (MPC_GLOBAL double *)((char *)w.G2 + (size_t)k * w.ld);
         double xx[12], uu[6];
 #pragma unroll
         for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
@@ -1001,14 +1071,24 @@ SE_PASS double nlp_res_pass(double *res4)
     Bundle<2> bin;
     Bundle<1> bout;
     {
-        const Seg si[2] = {segd(w.G1, W1, 0, W1), segd(w.G2, W2, 0, W2_LIN)};
+        const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)};
         bin.setup(si, lane);
-        const Seg so[1] = {segd(w.G2, W2, O_BD, 12)};
+        const Seg so[1] = {segd(w.G2, w.ld, O_BD, 12)};
         bout.setup(so, lane);
     }
     double csum = 0.0, a_s = 0, a_e = 0, a_i = 0, a_c = 0;
+    // per-lane parameters in registers for the whole sweep (see residual_pass)
+    const int jd = lane < 12 ? lane % 6 : 0;                                  // lanes 0..11: dynamics row / cost share
+    const double d_a = lane < 6 ? P.a12[jd] : P.a22[jd], d_b = lane < 6 ? P.b1[jd] : P.b2[jd], d_cq = P.cq[jd];
+    const double d_wt = P.w_task[lane >= 6 && lane < 6 + NTASK ? lane - 6 : 0];
+    const int ci = lane >= 16 && lane < 34 ? lane - 16 : 0, cls = ci / 6, cj = ci - cls * 6;   // lanes 16..33: stationarity row
+    const bool c_lo = cls < 2 && bnd_lo(P, ci < NB ? ci : 0) > -BOUND_INF, c_hi = cls < 2 && bnd_hi(P, ci < NB ? ci : 0) < BOUND_INF;
+    const double cb_lo = bnd_lo(P, ci < NB ? ci : 0), cb_hi = bnd_hi(P, ci < NB ? ci : 0);
+    const double k_dt = P.dt, k_2wu = 2.0 * P.w_u, k_wq = P.w_qddot, k_c2 = P.w_qddot * P.cq[cj] * P.cq[cj];
+    const double k_p1 = cls == 0 ? P.b1[cj] : P.a12[cj], k_p2 = cls == 0 ? P.b2[cj] : P.a22[cj];
+    const double xh = lane >= 48 && lane < 60 ? sm.xhat[lane - 48] : 0.0;
     if (lane < NX) sm.vec[0][lane] = 0.0;
-    sweep<2, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
+    sweep<78, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
         double *cur = rg.row(k), *nxt = rg.row(k + 1);
         double *o = sm.out[k & 1];
         const double *r1 = cur, *r2 = cur + I_L;
@@ -1016,42 +1096,69 @@ SE_PASS double nlp_res_pass(double *res4)
             // dynamics defect (prediction_model.py:317-320) and this stage's share of the cost
             double v = 0.0;
             if (k < N) {
-                const int j = lane % 6;
+                const int j = jd;
                 const double xq = r1[O_X + j], xv = r1[O_X + 6 + j], uj = r1[O_U + j];
-                v = lane < 6 ? (xq + P.a12[j] * xv + P.b1[j] * uj) - nxt[O_X + j] : (P.a22[j] * xv + P.b2[j] * uj) - nxt[O_X + 6 + j];
+                v = lane < 6 ? (xq + d_a * xv + d_b * uj) - nxt[O_X + j] : (d_a * xv + d_b * uj) - nxt[O_X + 6 + j];
                 a_e = fmax(a_e, fabs(v));
                 if (lane < 6) {
-                    const double qdd = P.cq[j] * (uj - xv);
-                    csum += 0.5 * P.dt * (2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd);
+                    const double qdd = d_cq * (uj - xv);
+                    csum += 0.5 * k_dt * (k_2wu * uj * uj + k_wq * qdd * qdd);
                 } else if (lane < 6 + NTASK) {
                     const double r = r2[O_R + (lane - 6)];
-                    csum += 0.5 * P.dt * P.w_task[lane - 6] * r * r;
+                    csum += 0.5 * k_dt * d_wt * r * r;
                 }
             }
             o[lane] = v;
         } else if (lane >= 16 && lane < 34 && res4) {
-            const int ci = lane - 16, cls = ci / 6, j = ci - cls * 6;
+            const int j = cj;
             const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
-            double v = cls == 0 ? stat_cls<0>(N, k, j, r1, r2, false, pk, pm)
-                     : cls == 1 ? stat_cls<1>(N, k, j, r1, r2, false, pk, pm) : stat_cls<2>(N, k, j, r1, r2, false, pk, pm);
-            if (ci < NB && has_comp(N, k, ci)) {
+            // stationarity of the NLP at the iterate (mpc_core.h stat_cls without delta), same operation order
+            double v = 0.0;
+            if (cls == 0) {
+                if (k < N) {
+                    const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+                    v = k_dt * (k_2wu * uj + k_c2 * (uj - vj));
+                    v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                }
+            } else if (cls == 1) {
+                if (k > 0) {
+                    if (k < N) {
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) s_ += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
+                        v = k_dt * s_ + pk[j];
+                    }
+                    v -= pm[j];
+                }
+            } else {
+                if (k > 0) {
+                    if (k < N) {
+                        const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+                        v = k_dt * (r2[O_GV + j] * r2[O_Y + 4] + k_c2 * (vj - uj));
+                        v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                    }
+                    v -= pm[6 + j];
+                }
+            }
+            const bool hc = cls == 0 ? k < N : (cls == 1 && k >= 1 && k < N);
+            if (hc) {
                 const double curv = r1[ci < 6 ? O_U + ci : O_X + ci - 6];
                 const double *lam = r1 + O_QLAM, *tt = r1 + O_QT;
-                if (bnd_lo(P, ci) > -BOUND_INF) {
+                if (c_lo) {
                     v -= lam[ci];
-                    a_i = fmax(a_i, fabs((bnd_lo(P, ci) - curv) + tt[ci]));
+                    a_i = fmax(a_i, fabs((cb_lo - curv) + tt[ci]));
                     a_c = fmax(a_c, fabs(lam[ci] * tt[ci]));
                 }
-                if (bnd_hi(P, ci) < BOUND_INF) {
+                if (c_hi) {
                     v += lam[12 + ci];
-                    a_i = fmax(a_i, fabs((curv - bnd_hi(P, ci)) + tt[12 + ci]));
+                    a_i = fmax(a_i, fabs((curv - cb_hi) + tt[12 + ci]));
                     a_c = fmax(a_c, fabs(lam[12 + ci] * tt[12 + ci]));
                 }
             }
             if (ci >= 6 && k == 0) v = 0.0;
             a_s = fmax(a_s, fabs(v));
         } else if (lane >= 48 && lane < 60) {
-            if (k == 0 && res4) a_i = fmax(a_i, fabs(sm.xhat[lane - 48] - r1[O_X + lane - 48]));   // lbx_0 = ubx_0 = x_hat
+            if (k == 0 && res4) a_i = fmax(a_i, fabs(xh - r1[O_X + lane - 48]));   // lbx_0 = ubx_0 = x_hat
             sm.vec[(k + 1) & 1][lane - 48] = cur[O_QPI + lane - 48];
         }
         fence();
@@ -1139,7 +1246,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         fence();
         for (int e = lane; e < (N + 1) * NX; e += WAVE) {
             const int k = e / NX, i = e - k * NX;
-            w.G1[(size_t)k * W1 + O_X + i] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
+            w.G1[(size_t)k * (w.ld / 8) + O_X + i] = i < 6 ? P.q0[i] : P.qdot0[i - 6];
         }
         if (lane < NX) sm.xhat[lane] = lane < 6 ? P.q0[lane] : P.qdot0[lane - 6];
         if (lane < NU) sm.u0[lane] = P.qdot0[lane];                   // u[:,0] = qdot_0 (simulator.py:81)
