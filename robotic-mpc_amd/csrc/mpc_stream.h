@@ -193,9 +193,13 @@ SE_DEV void dma_issue(const Bundle<NI> &b, int k, double *slot)
 {
 #pragma unroll
     for (int j = 0; j < NI; j++)
+#ifndef MPCB_NODMA
         if (b.g[j])
             __builtin_amdgcn_global_load_lds((const MPC_GLOBAL void *)(b.g[j] + (long long)k * b.stride[j]),
                                              (MPC_LOCAL void *)(slot + j * 2 * WAVE), 16, 0, 0);
+#else
+        (void)k, (void)slot;
+#endif
 }
 template <int NI>
 SE_DEV void store_out(const Bundle<NI> &b, int k, const double *lds, int lane)
@@ -348,7 +352,7 @@ SE_PASS IpmNorms residual_pass(double a)
     const double cb_lo = bnd_lo(P, ci < NB ? ci : 0), cb_hi = bnd_hi(P, ci < NB ? ci : 0);
     const double k_dt = P.dt, k_2wu = 2.0 * P.w_u, k_c2 = P.w_qddot * P.cq[cj] * P.cq[cj], k_lm = P.lm;
     const double k_p1 = cls == 0 ? P.b1[cj] : P.a12[cj], k_p2 = cls == 0 ? P.b2[cj] : P.a22[cj];
-    const double k_wt = P.w_task[lane < NTASK ? lane : 0];
+    const double k_wy = P.w_task[lane >= 48 && lane < 48 + NTASK ? lane - 48 : 0];
     const double k_ra = lj < 6 ? P.a12[lj] : P.a22[lj - 6], k_rb = lj < 6 ? P.b1[lj] : P.b2[lj - 6];
     const double xh = lane < NX ? sm.xhat[lane] : 0.0;
     // update of one landed row: dw += a ddw ; (lam, t) += a (dlam, dt) -- or the warm-start clamp in mode 0
@@ -386,24 +390,24 @@ SE_PASS IpmNorms residual_pass(double a)
 #ifdef MPCB_NOCOMPUTE
         (void)cur; (void)nxt; store_out(bout, k, o, lane); return;
 #endif
-        if (k == 0) upd_row(cur, 0);
+        if (k == 0) { upd_row(cur, 0); fence(); }
         // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
+        //      Y (lanes 48..52): y_i = w_i (r_i + G_i . delta_k) -- dw_k was updated when row k was the lookahead row
         if (k + 1 <= N) {
             upd_row(nxt, k + 1);
             if (MODE == 1 && lane >= 32 && lane < 44) cur[O_QPI + lane - 32] += a * nxt[I_D + 18 + lane - 32];
         }
-        fence();
-        // ---- Y: y_i = w_i (r_i + G_i . delta_k)
-        if (lane < NTASK && k < N) {
+        if (lane >= 48 && lane < 48 + NTASK && k < N) {
+            const int i = lane - 48;
             const double *r2 = cur + I_L, *dw = cur + O_QW;
-            double v = r2[O_R + lane];
+            double v = r2[O_R + i];
 #pragma unroll
-            for (int j = 0; j < 6; j++) v += r2[O_GQ + lane * 6 + j] * dw[6 + j];
-            if (lane == 4) {
+            for (int j = 0; j < 6; j++) v += r2[O_GQ + i * 6 + j] * dw[6 + j];
+            if (i == 4) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
             }
-            cur[I_L + O_Y + lane] = k_wt * v;
+            cur[I_L + O_Y + i] = k_wy * v;
         }
         fence();
         // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29)
@@ -488,13 +492,16 @@ SE_PASS IpmNorms residual_pass(double a)
                     a_b = fmax(a_b, fabs(v));
                 }
                 o[O_G + 30 + i] = v;
+            } else if (lane >= 32) {
+                // the updated QW..QT of this stage and r, y go out with the residual records (39 + 5 items, two per
+                // lane where needed); pi_k for the next stage
+                const int l = lane - 32;
+                ((MPC_LOCAL D2 *)(o + O_W))[l] = ((MPC_LOCAL D2 *)(cur + O_QW))[l];
+                if (l < 7) ((MPC_LOCAL D2 *)(o + O_W))[32 + l] = ((MPC_LOCAL D2 *)(cur + O_QW))[32 + l];
+                else if (l < 12) ((MPC_LOCAL D2 *)(o + O_RY))[l - 7] = ((MPC_LOCAL D2 *)(cur + I_L))[l - 7];
+                else if (l >= 16 && l < 28) sm.vec[(k + 1) & 1][l - 16] = cur[O_QPI + l - 16];
             }
         }
-        fence();
-        // the updated QW..QT of this stage and r, y go out with the residual records; pi_k for the next stage
-        if (lane < 39) ((MPC_LOCAL D2 *)(o + O_W))[lane] = ((MPC_LOCAL D2 *)(cur + O_QW))[lane];
-        else if (lane < 44) ((MPC_LOCAL D2 *)(o + O_RY))[lane - 39] = ((MPC_LOCAL D2 *)(cur + I_L))[lane - 39];
-        else if (lane >= 48 && lane < 60) sm.vec[(k + 1) & 1][lane - 48] = cur[O_QPI + lane - 48];
         fence();
         store_out(bout, k, o, lane);
     });
@@ -558,6 +565,9 @@ SE_PASS void fact_pass()
 #pragma unroll
     for (int i = 0; i < 6; i++) { b1r[i] = (FT)P.b1[i]; b2r[i] = (FT)P.b2[i]; }
     FT pr = (FT)0;                                                // vector lanes: p_{k+1}[jv]
+    int tro[12];                                                  // packed offsets of row jv of the symmetric P (constant indices only)
+#pragma unroll
+    for (int j = 0; j < NX; j++) tro[j] = tri_sym(jv, j);
     const FT lmN = (FT)P.lm;
     int sb = 0;
     auto next_stage = [&](FT gam_u, int sbw) {
@@ -653,7 +663,7 @@ SE_PASS void fact_pass()
                 // t = p_{k+1} + P_{k+1} rb_k
                 FT w0 = (FT)0, w1 = (FT)0;
 #pragma unroll
-                for (int j = 0; j < NX; j += 2) { w0 += facn[SPM + tri_sym(jv, j)] * (FT)rbv[j]; w1 += facn[SPM + tri_sym(jv, j + 1)] * (FT)rbv[j + 1]; }
+                for (int j = 0; j < NX; j += 2) { w0 += facn[SPM + tro[j]] * (FT)rbv[j]; w1 += facn[SPM + tro[j + 1]] * (FT)rbv[j + 1]; }
                 const FT wv = w0 + w1;
                 fac[SWV + jv] = wv;
                 sm.vec[1][jv] = (double)(pr + wv);
@@ -757,6 +767,9 @@ SE_PASS StepInfo forward_pass()
     const int j6 = j12 % 6;
     const FT a12 = (FT)P.a12[j6], a22 = (FT)P.a22[j6], b1 = (FT)P.b1[j6], b2 = (FT)P.b2[j6];
     double al = 1.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    int tro[12];                                                   // dpi role: packed offsets of its row of P
+#pragma unroll
+    for (int i = 0; i < NX; i++) tro[i] = tri_sym(lane >= 32 && lane < 44 ? lane - 32 : 0, i);
     const int jl = lane >= 48 && lane < 60 ? lane - 48 : 0;        // lagging role: bounded component
     const bool jl_lo = bnd_lo(P, jl) > -BOUND_INF, jl_hi = bnd_hi(P, jl) < BOUND_INF;
     if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
@@ -793,7 +806,7 @@ SE_PASS StepInfo forward_pass()
             if (k >= 1) {
                 FT s0 = fac[SPV + j], s1 = (FT)0;
 #pragma unroll
-                for (int i = 0; i < NX; i += 2) { s0 += fac[SPM + tri_sym(j, i)] * (FT)dxk[i]; s1 += fac[SPM + tri_sym(j, i + 1)] * (FT)dxk[i + 1]; }
+                for (int i = 0; i < NX; i += 2) { s0 += fac[SPM + tro[i]] * (FT)dxk[i]; s1 += fac[SPM + tro[i + 1]] * (FT)dxk[i + 1]; }
                 v = (double)(s0 + s1);
             }
             o[18 + j] = v;                                          // DPI slot of stage k holds dpi_{k-1}
@@ -972,8 +985,8 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out)
         else if (it >= qp_iter_max) stop = 1;
         else if (!(alpha > 1e-12)) stop = 2;
         stop = uni(stop);
-#ifdef MPCB_NOCOMPUTE
-        stop = it >= 3 ? 0 : -1;     // memory-only timing build: three iterations per QP, whatever the (meaningless) norms say
+#if defined(MPCB_NOCOMPUTE) || defined(MPCB_FIXED_IT)
+        stop = it >= 3 ? 0 : -1;     // timing builds: three iterations per QP, whatever the (meaningless) norms say
 #endif
         if (stop >= 0) { status = stop; break; }
         SPROF_T0(tf);
