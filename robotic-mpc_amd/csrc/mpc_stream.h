@@ -378,8 +378,9 @@ SE_PASS IpmNorms residual_pass(double a)
                 const double *dl = row + I_D + 30, *dt = row + I_D + 54;
                 const double l0 = lam[j], t0 = t[j], l1 = lam[12 + j], t1 = t[12 + j];
                 const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
-                if (blo) { lam[j] = fmax(l0 + a * d0, 1e-16); t[j] = fmax(t0 + a * e0, 1e-16); }
-                if (bhi) { lam[12 + j] = fmax(l1 + a * d1, 1e-16); t[12 + j] = fmax(t1 + a * e1, 1e-16); }
+                // (selects, not branches: every exec-mask branch costs scalar instructions and a bubble)
+                lam[j] = blo ? fmax(l0 + a * d0, 1e-16) : l0; t[j] = blo ? fmax(t0 + a * e0, 1e-16) : t0;
+                lam[12 + j] = bhi ? fmax(l1 + a * d1, 1e-16) : l1; t[12 + j] = bhi ? fmax(t1 + a * e1, 1e-16) : t1;
             }
         }
     };
@@ -452,28 +453,25 @@ SE_PASS IpmNorms residual_pass(double a)
                     const bool hc = cls == 0 ? k < N : (k >= 1 && k < N);
                     const bool blo = hc && c_lo, bhi = hc && c_hi;
                     const double v_ = r1[cls == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
-                    double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
                     const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
-                    if (blo) {
-                        const double l = l_lo, t = t_lo, it = fast_rcp(t);
-                        rdl = dv - (cb_lo - v) - t;
-                        rml = l * t;
-                        rg -= l; gt -= l;
-                        gam += l * it;
-                        gt += (rml + l * rdl) * it;
-                        a_mu += rml;
-                        a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
-                    }
-                    if (bhi) {
-                        const double l = l_hi, t = t_hi, it = fast_rcp(t);
-                        rdu = (cb_hi - v) - dv - t;
-                        rmu = l * t;
-                        rg += l; gt += l;
-                        gam += l * it;
-                        gt -= (rmu + l * rdu) * it;
-                        a_mu += rmu;
-                        a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
-                    }
+                    // both sides are evaluated in every lane and masked by selects (an absent bound holds lam = 0, t = 1:
+                    // its terms are exact zeros or are deselected), in the operation order of the branchy form
+                    const double it_lo = fast_rcp(t_lo), it_hi = fast_rcp(t_hi);
+                    const double rdl = blo ? dv - (cb_lo - v) - t_lo : 0.0, rml = blo ? l_lo * t_lo : 0.0;
+                    const double rdu = bhi ? (cb_hi - v) - dv - t_hi : 0.0, rmu = bhi ? l_hi * t_hi : 0.0;
+                    double gam = 0.0;
+                    rg = blo ? rg - l_lo : rg;
+                    gt = blo ? gt - l_lo : gt;
+                    gam = blo ? gam + l_lo * it_lo : gam;
+                    gt = blo ? gt + (rml + l_lo * rdl) * it_lo : gt;
+                    a_mu = blo ? a_mu + rml : a_mu;
+                    a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                    rg = bhi ? rg + l_hi : rg;
+                    gt = bhi ? gt + l_hi : gt;
+                    gam = bhi ? gam + l_hi * it_hi : gam;
+                    gt = bhi ? gt - (rmu + l_hi * rdu) * it_hi : gt;
+                    a_mu = bhi ? a_mu + rmu : a_mu;
+                    a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
                     o[O_3 + O_RD + ci] = rdl; o[O_3 + O_RD + 12 + ci] = rdu;
                     o[O_3 + O_RM + ci] = rml; o[O_3 + O_RM + 12 + ci] = rmu;
                     o[O_G + ci] = gam;
@@ -1285,10 +1283,14 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         const bool ok = qs == 0 || qs == 1;
         if (!ok) status = 4;                                           // ACADOS_QP_FAILURE, iterate untouched
         __builtin_amdgcn_s_waitcnt(0);
+        SPROF_T0(tl);
         lin_pass(1.0, ok);
         __builtin_amdgcn_s_waitcnt(0);                                 // the records written lane by lane are complete before they are streamed
         fence();
+        SPROF_ADD(8, tl);
+        SPROF_T0(tn);
         const double cost = unid(nlp_res_pass(res4));
+        SPROF_ADD(9, tn);
         lin_valid = true;
         lin_cost = cost;
         __builtin_amdgcn_s_waitcnt(0);

@@ -18,4 +18,4 @@ for B in [int(v) for v in sys.argv[1:]] or [1024, 2048]:
     names = ["fact", "fwd_aff", "corr", "fwd", "resid", "ipm_total", "nlp_step_total"]
     print(f"B={B}: kernel {ms:.1f} ms for {pb.Nsim} steps; sim {B//2}: {it:.0f} IPM iterations; per IPM iteration and stage (us): " +
           ", ".join(f"{n} {out[i]/it/101*1e6:.2f}" for i, n in enumerate(names[:5])) +
-          f"; per step: ipm {out[5]/pb.Nsim*1e6:.0f} us, nlp_step {out[6]/pb.Nsim*1e6:.0f} us", flush=True)
+          f"; per step: ipm {out[5]/pb.Nsim*1e6:.0f} us, nlp_step {out[6]/pb.Nsim*1e6:.0f} us, lin_pass {out[8]/pb.Nsim*1e6:.0f} us, nlp_res {out[9]/pb.Nsim*1e6:.0f} us", flush=True)
