@@ -148,3 +148,36 @@ def test_fp32_riccati_rejected_for_full_sqp(ur10):
 
     with pytest.raises(ValueError, match="SQP_RTI"):
         config.resolve_config(config.base_params(riccati_precision="fp32", solver_options={"nlp_solver_type": "SQP"}))
+
+
+def test_stream_engine_full_size_batch_is_deterministic_and_matches_oracle(orc, ur10, ur10_rb, monkeypatch):
+    """The throughput geometry at its real size: 2048 simulations (two wavefronts per SIMD on every CU), N = 100,
+    600 closed-loop steps, SQP_RTI (the workload of VERDICT r1 item 4, one residency round).  Identical simulations at
+    different batch positions give bitwise identical logs (no cross-wavefront interference), a second run repeats the
+    first bit for bit, and spot checks meet the oracle at 1e-9 with identical iteration counts."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from robotic_mpc_amd import engine
+
+    monkeypatch.delenv("MPCB_ENGINE", raising=False)
+    cfgs = bench.workload_configs(2048, 100, 6.0, seed=4, solver="SQP_RTI")
+    cfgs[1000] = cfgs[7]
+    cfgs[2047] = cfgs[7]
+    e = engine.MpcBatchEngine(0)
+    try:
+        pb, bufs = e.run_device(cfgs, ur10)
+        assert e.launch_info()["engine"] == 1
+        keep = {k: bufs[k][[7, 1000, 2047, 1234]].cpu().numpy() for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "cost", "residuals",
+                                                                          "status", "sqp_iter", "qp_iter", "errors")}
+        zsum = bufs["z"].sum(dim=(1, 2)).cpu().numpy()
+        assert int((bufs["status"] != 0).sum().item()) == 0 and bool(bufs["z"].isfinite().all().item())
+        for k in ("z", "u", "cost", "qp_iter", "errors"):
+            assert np.array_equal(keep[k][0], keep[k][1]) and np.array_equal(keep[k][0], keep[k][2]), k
+        for row, i in ((0, 7), (3, 1234)):
+            ref = orc.run(ur10_rb, orc.make_params(cfgs[i]))
+            _check(keep, row, ref)
+        pb, bufs2 = e.run_device(cfgs, ur10)
+        assert np.array_equal(zsum, bufs2["z"].sum(dim=(1, 2)).cpu().numpy())
+        assert np.array_equal(keep["u"][3], bufs2["u"][1234].cpu().numpy())
+    finally:
+        e.close()
