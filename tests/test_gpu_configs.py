@@ -268,3 +268,21 @@ def test_two_rank_sharded_engine_run_equals_single_process(tmp_path):
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(line[0][len("DIST_ENGINE_CHECK "):])
     assert d["ok"] and d["sharded_equals_unsharded"] and d["world_size"] == 2 and d["n_sims"] == 13
+
+
+def test_reference_dump_comparer_end_to_end(orc, ur10_rb, tmp_path):
+    """`python -m robotic_mpc_amd.compare`: a dump in the reference-run format (here produced by the
+    oracle, standing in for acados) is re-run on the HIP engine and compared column by column."""
+    import json
+
+    from robotic_mpc_amd import base_params, compare, config
+
+    cfg = base_params(prediction_horizon=15, simulation_time=0.4, solver_options={"nlp_solver_type": "SQP"})
+    ref = _oracle_result(orc, ur10_rb, config.resolve_config(cfg))
+    jsonable = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in cfg.items()}
+    path = str(tmp_path / "ref_run.npz")
+    np.savez(path, config=json.dumps(jsonable), q=ref["z"][:6], qdot=ref["z"][6:], u=ref["u"],
+             **{k: ref["errors"][i] for i, k in enumerate(("e1", "e2", "e3", "e4", "e5"))}, solver_status=ref["status"])
+    rep = compare.compare_file(path, tol=1e-9)
+    assert rep["ok"] and rep["columns_compared"] == 41, rep
+    assert compare.main([path, "--tol", "1e-9"]) == 0

@@ -394,3 +394,31 @@ def test_riccati_precision_is_a_bucket_property():
         config.resolve_config(config.base_params(riccati_precision="fp16"))
     with pytest.raises(ValueError, match="SQP_RTI"):
         config.resolve_config(config.base_params(riccati_precision="fp32", solver_options={"nlp_solver_type": "SQP"}))
+
+
+def test_reference_dump_comparer(orc, tmp_path):
+    """compare.py: the array comparison behind `python -m robotic_mpc_amd.compare ref_run.npz` (the reference-run
+    dump format of INTEGRATION.md), exercised with an oracle run standing in for both sides."""
+    from robotic_mpc_amd import SimulationManager, compare
+
+    m = SimulationManager(_base(), runner=hp.oracle_runner)
+    m.sweep("w_u", [0.01])
+    r = m.run_all()[0]
+    sim, d = r["simulator"], r["data"]
+    ref = {"q": d["q"], "qdot": d["qdot"], "u": d["u"], **{k: sim.errors[k] for k in ("e1", "e2", "e3", "e4", "e5")}}
+    rep = compare.compare_arrays(ref, ref, 1e-6, sim.solver_status, sim.solver_status)
+    assert rep["ok"] and rep["columns_compared"] == 9 and max(rep["max_abs_diff"].values()) == 0.0
+    off = {k: v.copy() for k, v in ref.items()}
+    off["u"][2, 5] += 3e-6
+    rep = compare.compare_arrays(ref, off, 1e-6)
+    assert not rep["ok"] and rep["first_violation"] == {"u": 5} and rep["max_abs_diff"]["u"] == pytest.approx(3e-6)
+    st = np.zeros(8, dtype=int); st[3] = 2                                  # a flagged step ends the strict comparison
+    rep = compare.compare_arrays(ref, off, 1e-6, st, None)
+    assert rep["ok"] and rep["columns_compared"] == 4
+    # the dump format round-trips through npz
+    import json
+    cfg = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in _base().items()}
+    np.savez(tmp_path / "ref_run.npz", config=json.dumps(cfg), **ref, solver_status=sim.solver_status)
+    with np.load(tmp_path / "ref_run.npz") as f:
+        back = compare._config_from_npz(f)
+    assert back["prediction_horizon"] == _base()["prediction_horizon"] and np.allclose(back["q_0"], _base()["q_0"])
