@@ -83,7 +83,11 @@ typedef struct {
  *   [61] nlp_solver_tol_eq [62] nlp_solver_tol_ineq [63] nlp_solver_tol_comp -- 0 means "same as [1]", which is
  *        nlp_solver_tol_stat (any acados option reaches the solver through simulator.py:129-135)
  *   [64] levenberg_marquardt (acados: dt*lm*I added to every stage Hessian, lm*I to the terminal one)
- *   [65..71] reserved (0)
+ *   [65] this simulation's prediction horizon, when the simulations of one call have DIFFERENT horizons ("ragged"
+ *        batch, e.g. a grid search over prediction_horizon run as one launch): 1 <= [65] <= mpcb_problem.N, and
+ *        mpcb_problem.N is the largest of them; 0 means N.  Ragged batches run on the throughput engine only
+ *        (SQP_RTI); mpcb_setup rejects them otherwise.
+ *   [66..71] reserved (0)
  * Bounds with |value| >= 1e29 are treated as absent.
  *
  * Kinematic constants, MPCB_NROBOT doubles (what loader.py:24-36 extracts from the URDF):

@@ -412,11 +412,11 @@ void mpcb_destroy(mpcb_handle *h)
 
 const char *mpcb_last_error(const mpcb_handle *h) { return h ? h->err.c_str() : "invalid handle"; }
 
-// which kernel family runs `p` (see include/mpcbatch.h)
-static int pick_engine(const mpcb_problem *p)
+// which kernel family runs `p` (see include/mpcbatch.h); `ragged`: the simulations have different horizons
+static int pick_engine(const mpcb_problem *p, bool ragged = false)
 {
     if (p->solver_type != MPCB_SOLVER_SQP_RTI) return 0;
-    if (p->precision == MPCB_PRECISION_FP32_RICCATI) return 1;
+    if (p->precision == MPCB_PRECISION_FP32_RICCATI || ragged) return 1;
     int e = p->batch >= MPCB_STREAM_MIN_BATCH ? 1 : 0;
     if (const char *env = getenv("MPCB_ENGINE")) {
         if (!strcmp(env, "stream")) e = 1;
@@ -424,9 +424,9 @@ static int pick_engine(const mpcb_problem *p)
     }
     return e;
 }
-static size_t ws_doubles_for(const mpcb_problem *p)
+static size_t ws_doubles_for(const mpcb_problem *p, bool ragged = false)
 {
-    if (pick_engine(p) == 0) return ws_doubles_per_instance(p->N);
+    if (pick_engine(p, ragged) == 0) return ws_doubles_per_instance(p->N);
     return p->precision == MPCB_PRECISION_FP32_RICCATI ? se::sws_doubles_per_instance<float>(p->N) : se::sws_doubles_per_instance<double>(p->N);
 }
 
@@ -451,8 +451,14 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
     if (!params_host || !robot_host) return fail(h, MPCB_EINVAL, "params/robot pointer is NULL");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<InstParams> packed((size_t)p->batch);
+    bool ragged = false;
     for (int i = 0; i < p->batch; i++) {
         const double *pp = params_host + (size_t)i * MPCB_NPARAM;
+        if (pp[65] != 0.0) {
+            if (!(pp[65] >= 1.0 && pp[65] <= (double)p->N) || pp[65] != std::floor(pp[65]))
+                return fail(h, MPCB_EINVAL, "per-simulation horizon (parameter [65]) must be an integer in [1, N]");
+            if ((int)pp[65] != p->N) ragged = true;
+        }
         if (!(pp[0] > 0.0)) return fail(h, MPCB_EINVAL, "dt must be positive");
         for (int j = 0; j < 6; j++)
             if (!(pp[8 + j] > 0.0)) return fail(h, MPCB_EINVAL, "wcv must be positive");
@@ -470,9 +476,11 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         h->params_cap = pbytes;
     }
     HIPCHK(h, hipMemcpy(h->d_params, packed.data(), pbytes, hipMemcpyHostToDevice));
-    h->engine = pick_engine(p);
-    h->ws_stride = ws_doubles_for(p);
-    const size_t wbytes = mpcb_workspace_bytes(p);
+    if (ragged && p->solver_type != MPCB_SOLVER_SQP_RTI)
+        return fail(h, MPCB_EINVAL, "simulations with different horizons in one call need SQP_RTI (throughput engine)");
+    h->engine = pick_engine(p, ragged);
+    h->ws_stride = ws_doubles_for(p, ragged);
+    const size_t wbytes = (size_t)p->batch * h->ws_stride * sizeof(double);
     if (wbytes > h->ws_cap) {
         if (h->d_ws) (void)hipFree(h->d_ws);
         h->d_ws = nullptr; h->ws_cap = 0;

@@ -99,7 +99,8 @@ struct InstParams {
     double a12[6], a22[6], b1[6], b2[6];
     double cq[6];       // qddot gain (1-a22)/Ts
     // acados nlp_solver_tol_eq / _ineq / _comp (`tol` above is nlp_solver_tol_stat)
-    double tol_eq, tol_ineq, tol_comp, pad2;
+    double tol_eq, tol_ineq, tol_comp;
+    double n_hor;       // this simulation's prediction horizon when it differs from the launch's (throughput engine: ragged batches); 0 = Problem::N
 };
 
 // Batch-uniform problem description (== mpcb_problem).

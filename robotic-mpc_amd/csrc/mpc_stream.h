@@ -1233,7 +1233,9 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
 {
     SSmem &sm = g_ssm;
     const int lane = threadIdx.x;
-    const int N = pb.N, Nsim = pb.Nsim, T1 = Nsim + 1;
+    // ragged batch: this simulation's own horizon (the workspace stride is sized for the longest)
+    const double nh = params[inst].n_hor;
+    const int N = uni(nh > 0.0 ? (int)nh : pb.N), Nsim = pb.Nsim, T1 = Nsim + 1;
     {
         const double *ps = reinterpret_cast<const double *>(params + inst);
         double *pd = reinterpret_cast<double *>(&sm.P);
@@ -1241,7 +1243,12 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         const double *rs = reinterpret_cast<const double *>(rbp);
         double *rd = reinterpret_cast<double *>(&sm.rb);
         for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) rd[e] = rs[e];
-        if (lane == 0) { sm.w = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N); sm.n_hor = N; }
+        if (lane == 0) {
+            SWs ws = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N);
+            ws.state = ws_base + (size_t)inst * ws_stride + (ws_stride - STATE_DOUBLES);   // at the end of the stride whatever this simulation's horizon
+            sm.w = ws;
+            sm.n_hor = N;
+        }
     }
     fence();
     const InstParams &P = sm.P;
@@ -1252,8 +1259,9 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     int log_lo = step0 == 0 ? 0 : step0 + 1;
     if (step0 == 0) {
         // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0
-        const size_t tot = sws_doubles_per_instance<FT>(N);
+        const size_t tot = sws_doubles_per_instance<FT>(N) - STATE_DOUBLES;
         for (size_t e = lane; e < tot; e += WAVE) w.G1[e] = 0.0;      // G1 is the workspace base
+        if (lane < STATE_DOUBLES) w.state[lane] = 0.0;
         fence();
         for (int e = lane; e < (N + 1) * NX; e += WAVE) {
             const int k = e / NX, i = e - k * NX;

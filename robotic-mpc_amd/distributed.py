@@ -59,12 +59,45 @@ def chunk_bounds(n: int, parts: int) -> List[Tuple[int, int]]:
     return out
 
 
-def group_buckets(resolved: Sequence[Dict]) -> "OrderedDict[tuple, List[int]]":
-    """Queue indices grouped by launch bucket, first-appearance order."""
+def group_buckets(resolved: Sequence[Dict], parts: int = 1, merge_ragged: bool = True) -> "OrderedDict[tuple, List[int]]":
+    """Queue indices grouped by launch bucket, first-appearance order.
+
+    SQP_RTI buckets that differ only in the prediction horizon are merged into one RAGGED bucket when every one of
+    the `parts` ranks then gets at least packing.RAGGED_MIN_BATCH simulations of it: the throughput engine takes the
+    horizon per simulation, and a grid search over prediction_horizon (BASELINE configs[2]) then fills the GPU with
+    one launch instead of one under-filled launch per horizon.  Inside a ragged bucket the simulations are ordered so
+    that every contiguous shard holds the same mix of horizons, longest first (they are dispatched first)."""
     buckets: "OrderedDict[tuple, List[int]]" = OrderedDict()
     for i, c in enumerate(resolved):
         buckets.setdefault(packing.bucket_key(c), []).append(i)
-    return buckets
+    if not merge_ragged:
+        return buckets
+    groups: "OrderedDict[tuple, List[tuple]]" = OrderedDict()
+    for key, idxs in buckets.items():
+        c = resolved[idxs[0]]
+        if c["solver_type"] == packing.SOLVER_RTI:
+            groups.setdefault(packing.bucket_key(c, ragged=True), []).append(key)
+    out: "OrderedDict[tuple, List[int]]" = OrderedDict()
+    merged_members = {}
+    for rkey, keys in groups.items():
+        total = sum(len(buckets[k]) for k in keys)
+        if len(keys) > 1 and total // max(parts, 1) >= packing.RAGGED_MIN_BATCH:
+            for k in keys:
+                merged_members[k] = rkey
+    done = set()
+    for key, idxs in buckets.items():
+        rkey = merged_members.get(key)
+        if rkey is None:
+            out[key] = idxs
+        elif rkey not in done:
+            done.add(rkey)
+            members = [k for k in groups[rkey]]
+            # longest horizon first, then round-robin over the shards so that each contiguous chunk gets the same mix
+            allidx = sorted((i for k in members for i in buckets[k]), key=lambda i: -resolved[i]["N"])
+            p = max(parts, 1)
+            shards = [allidx[r::p] for r in range(p)]
+            out[("ragged",) + rkey] = [i for sh in shards for i in sh]
+    return out
 
 
 def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[str, np.ndarray]]:
@@ -122,7 +155,7 @@ def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Calla
 
     ws, me = (world_size(), rank()) if use_dist else (1, 0)
     records: List[Optional[Dict[str, np.ndarray]]] = [None] * len(resolved)
-    buckets = list(group_buckets(resolved).items())
+    buckets = list(group_buckets(resolved, ws, getattr(runner, "supports_ragged", False)).items())
     kernel_ms, d2h_s = 0.0, 0.0
     # a runner with submit()/collect() launches buckets before the first result is awaited (buckets smaller than
     # the GPU then overlap); a plain callable runs them one after the other.  At most `max_in_flight` buckets hold

@@ -104,11 +104,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 def make_problem(cfgs: Sequence[Dict]) -> MpcbProblem:
     c0 = cfgs[0]
-    key0 = packing.bucket_key(c0)
+    ragged = any(c["N"] != c0["N"] for c in cfgs)
+    if ragged and c0["solver_type"] != packing.SOLVER_RTI:
+        raise ValueError("simulations of different horizons share a launch only with nlp_solver_type='SQP_RTI'")
+    key0 = packing.bucket_key(c0, ragged)
     for c in cfgs[1:]:
-        if packing.bucket_key(c) != key0:
-            raise ValueError("all simulations of one launch must share N, Nsim, solver options and robot")
-    return MpcbProblem(len(cfgs), c0["N"], c0["Nsim"], c0["solver_type"], c0["max_iter"], c0["qp_iter_max"],
+        if packing.bucket_key(c, ragged) != key0:
+            raise ValueError("all simulations of one launch must share Nsim, solver options and robot (and N, except SQP_RTI)")
+    return MpcbProblem(len(cfgs), max(c["N"] for c in cfgs), c0["Nsim"], c0["solver_type"], c0["max_iter"], c0["qp_iter_max"],
                        int(c0["fixed_step"]), int(c0.get("precision", 0)))
 
 

@@ -19,6 +19,7 @@ def pack_params(cfg: Dict) -> np.ndarray:
     p[50:56] = cfg["coeffs"]; p[56:61] = cfg["w_task"]
     p[61] = cfg.get("tol_eq", 0.0); p[62] = cfg.get("tol_ineq", 0.0); p[63] = cfg.get("tol_comp", 0.0)
     p[64] = cfg.get("levenberg_marquardt", 0.0)
+    p[65] = cfg["N"]    # per-simulation horizon: lets one launch hold simulations of different horizons (ragged bucket)
     return p
 
 
@@ -26,8 +27,15 @@ def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
     return np.ascontiguousarray(np.stack([pack_params(c) for c in cfgs]))
 
 
-def bucket_key(cfg: Dict):
-    """Instances that can share one launch: same horizon/steps/solver options and robot."""
+# SQP_RTI buckets that differ only in the prediction horizon are merged into one RAGGED launch of the throughput engine
+# once together they reach this many simulations (include/mpcbatch.h MPCB_STREAM_MIN_BATCH: two wavefronts per SIMD)
+RAGGED_MIN_BATCH = 2048
+SOLVER_RTI = 1
+
+
+def bucket_key(cfg: Dict, ragged: bool = False):
+    """Instances that can share one launch: same steps/solver options and robot, and the same horizon -- unless
+    `ragged` (throughput engine: the horizon is a per-simulation parameter, slot [65] of the record)."""
     return (cfg["robot_name"], cfg.get("urdf_path"), cfg.get("ee_frame"), tuple(np.asarray(cfg["t_ee"]).tolist()),
-            cfg["N"], cfg["Nsim"], cfg["solver_type"], cfg["max_iter"], cfg["qp_iter_max"], bool(cfg["fixed_step"]),
-            int(cfg.get("precision", 0)))
+            None if ragged else cfg["N"], cfg["Nsim"], cfg["solver_type"], cfg["max_iter"], cfg["qp_iter_max"],
+            bool(cfg["fixed_step"]), int(cfg.get("precision", 0)))

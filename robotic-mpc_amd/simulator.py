@@ -277,6 +277,7 @@ class _EngineRunner:
     gathers them across ranks (RCCL) or copies them to the host, once."""
 
     max_in_flight = 8   # buckets holding an engine + workspace + result buffers at the same time
+    supports_ragged = True   # SQP_RTI buckets that differ only in the horizon may arrive merged (throughput engine)
 
     def __init__(self, device: int):
         self.device = device
@@ -436,7 +437,8 @@ class SimulationManager:
         self.last_run_info = {"n_sims": len(sims), "n_resumed": len(done), "setup_s": t_run - t_start,
                               "run_s": time.time() - t_run, "kernel_ms": info.get("kernel_ms", 0.0),
                               "d2h_s": info.get("d2h_s", 0.0),
-                              "buckets": len({packing.bucket_key(resolved[i]) for i in todo}),
+                              "buckets": len(dmod.group_buckets([resolved[i] for i in todo], dmod.world_size() if use_dist else 1,
+                                                                getattr(runner, "supports_ragged", False))),
                               "world_size": dmod.world_size() if use_dist else 1}
         if new is None or (use_dist and dmod.rank() != 0):  # non-root rank
             return [] if return_results else None

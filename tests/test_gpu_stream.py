@@ -181,3 +181,36 @@ def test_stream_engine_full_size_batch_is_deterministic_and_matches_oracle(orc, 
         assert np.array_equal(keep["u"][3], bufs2["u"][1234].cpu().numpy())
     finally:
         e.close()
+
+
+def test_ragged_batch_runs_every_horizon_in_one_launch(orc, ur10, ur10_rb, monkeypatch):
+    """BASELINE configs[2] on one GPU: a grid search over prediction_horizon as ONE launch of the throughput engine
+    (horizon per simulation, parameter [65]).  Every simulation equals its own uniform-horizon run bit for bit and
+    meets the oracle; through SimulationManager the merged bucket shows up as one bucket."""
+    from robotic_mpc_amd import SimulationManager, base_params, engine
+
+    monkeypatch.delenv("MPCB_ENGINE", raising=False)
+    Ns = (20, 7, 33, 50)
+    cfgs = [c for N in Ns for c in _jitter(6, seed=N, prediction_horizon=N, simulation_time=0.3)]
+    e = engine.MpcBatchEngine(0)
+    try:
+        out = e.run(cfgs, ur10)                       # mixed horizons -> ragged -> throughput engine whatever the batch size
+        assert e.launch_info()["engine"] == 1
+        for g, N in enumerate(Ns):
+            monkeypatch.setenv("MPCB_ENGINE", "stream")
+            solo = e.run(cfgs[6 * g:6 * g + 6], ur10)
+            monkeypatch.delenv("MPCB_ENGINE")
+            for k in ("z", "u", "cost", "qp_iter", "status", "errors"):
+                assert np.array_equal(out[k][6 * g:6 * g + 6], solo[k]), (N, k)
+            _check(out, 6 * g + 1, orc.run(ur10_rb, orc.make_params(cfgs[6 * g + 1])))
+    finally:
+        e.close()
+    from robotic_mpc_amd import packing
+    monkeypatch.setattr(packing, "RAGGED_MIN_BATCH", 8)
+    m = SimulationManager(base_params(simulation_time=0.2))
+    m.grid_search({"prediction_horizon": [10, 20, 40], "w_qddot": [0.02, 0.05, 0.08]})
+    res = m.run_all()
+    assert m.last_run_info["buckets"] == 1 and len(res) == 9
+    ref = orc.run(ur10_rb, orc.make_params(res[4]["simulator"].resolved))
+    np.testing.assert_allclose(res[4]["data"]["u"], ref["u"], atol=ATOL, rtol=0)
+    assert res[4]["simulator"].prediction_horizon == 20 and (res[4]["simulator"].solver_status == 0).all()

@@ -422,3 +422,56 @@ def test_reference_dump_comparer(orc, tmp_path):
     with np.load(tmp_path / "ref_run.npz") as f:
         back = compare._config_from_npz(f)
     assert back["prediction_horizon"] == _base()["prediction_horizon"] and np.allclose(back["q_0"], _base()["q_0"])
+
+
+def test_ragged_buckets_merge_rti_horizons(orc, monkeypatch):
+    """SQP_RTI buckets that differ only in prediction_horizon merge into one ragged launch once every rank gets
+    RAGGED_MIN_BATCH simulations of it; each contiguous shard holds the same horizon mix, longest first; other solver
+    types and small queues keep one bucket per horizon; results come back in queue order either way."""
+    from robotic_mpc_amd import SimulationManager, config, distributed, packing
+
+    mk = lambda N, **kw: config.resolve_config({**_base(), "prediction_horizon": N, **kw})
+    res = [mk(N) for N in (4, 6, 8) for _ in range(4)] + [mk(6, solver_options={"nlp_solver_type": "SQP"}) for _ in range(3)]
+    assert len(distributed.group_buckets(res)) == 4                                    # below the threshold: per horizon
+    monkeypatch.setattr(packing, "RAGGED_MIN_BATCH", 5)
+    b = distributed.group_buckets(res, parts=2)
+    keys = list(b)
+    assert len(b) == 2 and keys[0][0] == "ragged" and len(b[keys[0]]) == 12 and len(b[keys[1]]) == 3
+    order = [res[i]["N"] for i in b[keys[0]]]
+    assert order[:6] == [8, 8, 6, 6, 4, 4] and order[6:] == [8, 8, 6, 6, 4, 4]         # two shards, same mix, longest first
+    assert len(distributed.group_buckets(res, parts=4)) == 4                           # 12 / 4 ranks < 5: no merge
+    assert len(distributed.group_buckets(res, parts=2, merge_ragged=False)) == 4
+    # end to end through run_all with a runner that accepts ragged buckets (the oracle runs every config by itself)
+    calls = []
+
+    class Runner:
+        supports_ragged = True
+
+        def __call__(self, cfgs, chain):
+            calls.append(sorted({c["N"] for c in cfgs}))
+            return hp.oracle_runner(cfgs, chain)
+
+    m = SimulationManager(_base(), runner=Runner())
+    m.grid_search({"prediction_horizon": [4, 6, 8], "w_qddot": [0.02, 0.05]})
+    out = m.run_all()
+    assert calls == [[4, 6, 8]] and m.last_run_info["buckets"] == 1
+    ref = SimulationManager(_base(), runner=hp.oracle_runner)
+    ref.grid_search({"prediction_horizon": [4, 6, 8], "w_qddot": [0.02, 0.05]})
+    for a, r in zip(out, ref.run_all()):
+        assert a["name"] == r["name"] and a["simulator"].prediction_horizon == r["simulator"].prediction_horizon
+        np.testing.assert_array_equal(a["data"]["u"], r["data"]["u"])
+    assert ref.last_run_info["buckets"] == 3
+
+
+def test_ragged_problem_construction():
+    from robotic_mpc_amd import config, engine, packing
+
+    a = config.resolve_config({**_base(), "prediction_horizon": 5})
+    b = config.resolve_config({**_base(), "prediction_horizon": 9})
+    pb = engine.make_problem([a, b, a])
+    assert pb.N == 9 and pb.batch == 3
+    assert packing.pack_params(a)[65] == 5 and packing.pack_params(b)[65] == 9
+    s = config.resolve_config({**_base(), "prediction_horizon": 9, "solver_options": {"nlp_solver_type": "SQP"}})
+    s5 = config.resolve_config({**_base(), "prediction_horizon": 5, "solver_options": {"nlp_solver_type": "SQP"}})
+    with pytest.raises(ValueError, match="SQP_RTI"):
+        engine.make_problem([s, s5])
