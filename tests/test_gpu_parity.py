@@ -243,3 +243,49 @@ def test_simulation_manager_end_to_end_on_gpu(orc):
             np.testing.assert_allclose(a["analysis"][k], b["analysis"][k], atol=1e-8)
         assert abs(a["summary"]["weighted_rmse"] - b["summary"]["weighted_rmse"]) < 1e-8
         assert a["summary"]["num_failures"] == 0
+
+
+FAILURE_CASES = {
+    # the reference only RECORDS solver failures (solver_status[i] = status, simulator.py:217) and
+    # carries on with whatever u the iterate holds; a batch must never abort.  acados codes: 2 max-iter, 4 QP failure.
+    "sqp_maxiter": dict(solver_options={"nlp_solver_type": "SQP", "nlp_solver_max_iter": 2}),
+    "qp_itermax_rti": dict(solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": 3}),
+    "qp_itermax_sqp": dict(solver_options={"nlp_solver_type": "SQP", "qp_solver_iter_max": 2}),
+    "infeasible_rti": dict(q_min_offset=0.5, solver_options={"nlp_solver_type": "SQP_RTI"}),
+    "infeasible_sqp": dict(q_min_offset=0.5, solver_options={"nlp_solver_type": "SQP"}),
+}
+
+
+def failure_case_config(name):
+    from robotic_mpc_amd import config
+
+    kw = dict(FAILURE_CASES[name])
+    off = kw.pop("q_min_offset", None)
+    if off is not None:
+        kw["q_min"] = config.BASE_PARAMS["q_0"] + off          # the initial state violates the position bounds: infeasible QP
+    return _cfg(prediction_horizon=10, simulation_time=0.15, **kw)
+
+
+@pytest.mark.parametrize("name", sorted(FAILURE_CASES))
+def test_solver_failures_are_data_and_match_the_oracle(eng, orc, ur10, ur10_rb, name):
+    c = failure_case_config(name)
+    out = eng.run([c, c], ur10)                      # (a failing simulation does not disturb its neighbour)
+    ref = orc.run(ur10_rb, orc.make_params(c))
+    expect = {"sqp_maxiter": 2, "infeasible_rti": 4, "infeasible_sqp": 4}.get(name, 0)
+    assert (ref["status"] == expect).all()
+    for i in (0, 1):
+        np.testing.assert_array_equal(out["status"][i], ref["status"], err_msg=name)
+        if name == "qp_itermax_sqp":
+            # QPs truncated after two interior-point iterations make the SQP path hinge on round-off at the 1e-6
+            # convergence test: the count may differ by one iteration, the converged steps agree to the NLP tolerance
+            assert np.abs(out["sqp_iter"][i] - ref["sqp_iter"]).max() <= 1
+            for k in ("z", "u"):
+                np.testing.assert_allclose(out[k][i], ref[k], atol=1e-5, rtol=0, err_msg=f"{name} {k}")
+            continue
+        np.testing.assert_array_equal(out["sqp_iter"][i], ref["sqp_iter"], err_msg=name)
+        # (an infeasible QP ends by HPIPM's min-step test on a diverging iteration: the count hinges on round-off)
+        assert np.abs(out["qp_iter"][i] - ref["qp_iter"]).max() <= (2 if name.startswith("infeasible") else 0), name
+        for k in ("z", "u", "ee_pose"):
+            np.testing.assert_allclose(out[k][i], ref[k], atol=1e-8, rtol=0, err_msg=f"{name} {k}")
+    assert np.isfinite(out["z"]).all()
+    assert np.array_equal(out["z"][0], out["z"][1])

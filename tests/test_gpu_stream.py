@@ -214,3 +214,22 @@ def test_ragged_batch_runs_every_horizon_in_one_launch(orc, ur10, ur10_rb, monke
     ref = orc.run(ur10_rb, orc.make_params(res[4]["simulator"].resolved))
     np.testing.assert_allclose(res[4]["data"]["u"], ref["u"], atol=ATOL, rtol=0)
     assert res[4]["simulator"].prediction_horizon == 20 and (res[4]["simulator"].solver_status == 0).all()
+
+
+@pytest.mark.parametrize("name", ["qp_itermax_rti", "infeasible_rti"])
+def test_stream_engine_solver_failures_match_the_oracle(stream_engine, orc, ur10, ur10_rb, name):
+    """Failures are data on this engine too (acados status 4 = QP failure: the iterate stays untouched)."""
+    sys.path.insert(0, HERE)
+    import test_gpu_parity as tp
+
+    c = tp.failure_case_config(name)
+    out = stream_engine.run([c, c], ur10)
+    ref = orc.run(ur10_rb, orc.make_params(c))
+    for i in (0, 1):
+        for k in ("status", "sqp_iter"):
+            np.testing.assert_array_equal(out[k][i], ref[k], err_msg=f"{name} {k}")
+        # an infeasible QP ends when the diverging iteration's step length underflows (HPIPM min-step): the iteration at
+        # which that happens hinges on round-off, the outcome (status 4, iterate untouched) does not
+        assert np.abs(out["qp_iter"][i] - ref["qp_iter"]).max() <= (2 if name.startswith("infeasible") else 0)
+        for k in ("z", "u", "ee_pose"):
+            np.testing.assert_allclose(out[k][i], ref[k], atol=1e-8, rtol=0, err_msg=f"{name} {k}")

@@ -369,3 +369,20 @@ def test_plant_integrators_against_their_butcher_tableaus(orc, code, tableau):
     order = {1: 1, 2: 2, 3: 3, 0: 4}[code]
     R = sum(h ** m / math.factorial(m) for m in range(order + 1))
     np.testing.assert_allclose(got[6:], R * z[6:] + (1 - R) * u, rtol=0, atol=1e-13)
+
+
+def test_oracle_records_solver_failures_and_carries_on(orc, ur10_rb):
+    """simulator.py:217 records solver.solve()'s status and the loop continues with whatever u the iterate holds
+    (SURVEY.md section 5).  acados codes: 2 = SQP max-iter, 4 = QP failure (iterate left untouched); a QP that merely
+    hits its iteration cap (HPIPM status 1) is accepted by acados."""
+    from robotic_mpc_amd import config
+
+    mk = lambda **kw: config.resolve_config(config.base_params(prediction_horizon=10, simulation_time=0.15, **kw))
+    r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP", "nlp_solver_max_iter": 2})))
+    assert (r["status"] == 2).all() and (r["sqp_iter"] == 2).all() and np.isfinite(r["z"]).all()
+    r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": 3})))
+    assert (r["status"] == 0).all() and (r["qp_iter"] == 3).all()
+    bad = mk(q_min=config.BASE_PARAMS["q_0"] + 0.5)          # the initial state violates the position bounds: infeasible QP
+    r = orc.run(ur10_rb, orc.make_params(bad))
+    assert (r["status"] == 4).all() and np.isfinite(r["z"]).all()
+    assert np.abs(r["u"][:, 1:]).max() == 0.0                # iterate untouched: u stays at the initial guess 0
