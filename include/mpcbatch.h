@@ -54,7 +54,7 @@ extern "C" {
 /* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 2-4
  * wavefronts and most of a CU's LDS per simulation; batches up to a few simulations per CU, and every SQP run) and
  * the THROUGHPUT engine (one wavefront per simulation, records streamed; SQP_RTI batches of >= MPCB_STREAM_MIN_BATCH
- * simulations, and every fp32-Riccati run).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
+ * simulations, every fp32-Riccati run, every ragged batch; it implements full SQP too, which MPCB_ENGINE=stream selects).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
  * overrides the choice where both apply. */
 #define MPCB_STREAM_MIN_BATCH 2048
 
@@ -85,8 +85,7 @@ typedef struct {
  *   [64] levenberg_marquardt (acados: dt*lm*I added to every stage Hessian, lm*I to the terminal one)
  *   [65] this simulation's prediction horizon, when the simulations of one call have DIFFERENT horizons ("ragged"
  *        batch, e.g. a grid search over prediction_horizon run as one launch): 1 <= [65] <= mpcb_problem.N, and
- *        mpcb_problem.N is the largest of them; 0 means N.  Ragged batches run on the throughput engine only
- *        (SQP_RTI); mpcb_setup rejects them otherwise.
+ *        mpcb_problem.N is the largest of them; 0 means N.  Ragged batches run on the throughput engine.
  *   [66..71] reserved (0)
  * Bounds with |value| >= 1e29 are treated as absent.
  *

@@ -21,9 +21,9 @@
 // recursions in fp32 -- half the bytes of the largest record; iterate, residuals, right-hand sides, step lengths,
 // multiplier steps and all logged outputs stay fp64).
 //
-// Algorithm and formulas: those of mpc_core.h (acados SQP_RTI + HPIPM Mehrotra IPM + Riccati, restated from
-// trajectory_optimizer.py:57-176 and simulator.py:199-241); see there for derivations.  Only SQP_RTI runs on this
-// engine (full SQP with its line search keeps the latency engine).
+// Algorithm and formulas: those of mpc_core.h (acados SQP / SQP_RTI + HPIPM Mehrotra IPM + Riccati, restated from
+// trajectory_optimizer.py:57-176 and simulator.py:199-241); see there for derivations.  Both solver types are
+// implemented; by default only SQP_RTI batches are sent here (mpc_kernel.hip pick_engine).
 #pragma once
 #include "mpc_core.h"
 
@@ -48,24 +48,26 @@ constexpr int SW4_AFF = SPV, SW4_FWD = SWV;
 struct SWs {
     double *G1, *G2, *G3;   // row 0 of each group inside the stage record
     char *G4;               // SW4 scalars of the factor type
+    double *G5;             // SQP extras (NLP multipliers, merit weights): present in SQP launches only
     double *state;
     int ld;                 // stage record stride (bytes)
 };
 template <class FT>
-MPC_HD size_t sws_doubles_per_instance(int N)
+MPC_HD size_t sws_doubles_per_instance(int N, bool sqp = false)
 {
-    return (size_t)(N + 1) * (W1 + W2 + W3 + SW4 * sizeof(FT) / 8) + STATE_DOUBLES;
+    return (size_t)(N + 1) * (W1 + W2 + W3 + SW4 * sizeof(FT) / 8 + (sqp ? W5 : 0)) + STATE_DOUBLES;
 }
 template <class FT>
-MPC_HD SWs sws_carve(double *base, int N)
+MPC_HD SWs sws_carve(double *base, int N, bool sqp = false)
 {
     const size_t n1 = (size_t)N + 1;
     SWs w;
-    w.ld = (W1 + W2 + W3) * 8 + SW4 * (int)sizeof(FT);
+    w.ld = (W1 + W2 + W3 + (sqp ? W5 : 0)) * 8 + SW4 * (int)sizeof(FT);
     w.G1 = base;
     w.G2 = base + W1;
     w.G3 = base + W1 + W2;
     w.G4 = (char *)(base + W1 + W2 + W3);
+    w.G5 = (double *)(w.G4 + SW4 * sizeof(FT));
     w.state = base + n1 * (size_t)(w.ld / 8);
     return w;
 }
@@ -1024,7 +1026,9 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out)
 // =============================================================================================== NLP passes (SQP_RTI)
 // Linearisation: lane <-> stage, straight from / to HBM (once per MPC step; each lane's 41 outputs land in its own
 // stage record, the L2 merges them into full lines).  Optionally applies the QP step first.
-SE_PASS void lin_pass(double alpha, bool do_update)
+// With `sqp_mult` the NLP multipliers are blended towards the QP's with the same step (acados
+// ocp_nlp_update_variables_sqp): N* += alpha (Q* - N*) on [pi | lam | t] (60 entries of G5).
+SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
 {
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
@@ -1049,6 +1053,10 @@ SE_PASS void lin_pass(double alpha, bool do_update)
 #pragma unroll
                 for (int i = 0; i < 6; i++) { uu[i] += alpha * r1[O_QW + i]; r1[O_U + i] = uu[i]; }
             }
+            if (sqp_mult) {
+                MPC_GLOBAL double *r5 = (MPC_GLOBAL double *)((char *)w.G5 + (size_t)k * w.ld);
+                for (int i = 0; i < 60; i++) r5[i] += alpha * (r1[O_QPI + i] - r5[i]);   // NPI | NLAM | NT <- QPI | QLAM | QT
+            }
         }
         double rec[W2_LIN];
         if (k < N) {
@@ -1071,6 +1079,8 @@ SE_PASS void lin_pass(double alpha, bool do_update)
 // Dynamics defect of the NLP iterate, cost = sum_k dt/2 r'Wr (acados get_cost()) and acados' ocp_nlp_res_compute
 // inf-norms [stat, eq, ineq, comp] with the QP multipliers (SQP_RTI).  Forward sweep, one row of lookahead (x_{k+1}).
 //   in : G1 row | G2 [R..GV]      out : G2 BD
+// SQPM: the residuals use the NLP multipliers of G5 (full SQP) instead of the QP's.
+template <bool SQPM>
 SE_PASS double nlp_res_pass(double *res4)
 {
     SSmem &sm = g_ssm;
@@ -1078,12 +1088,14 @@ SE_PASS double nlp_res_pass(double *res4)
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
-    constexpr int I_L = 96;
+    constexpr int I_L = 96, I_5 = 156;
+    constexpr int ITEMS = SQPM ? 108 : 78;
+    constexpr int MO_PI = SQPM ? I_5 + O_NPI : O_QPI, MO_LAM = SQPM ? I_5 + O_NLAM : O_QLAM, MO_T = SQPM ? I_5 + O_NT : O_QT;
     Bundle<2> bin;
     Bundle<1> bout;
     {
-        const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)};
-        bin.setup(si, lane);
+        if (SQPM) { const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN), segd(w.G5, w.ld, 0, 60)}; bin.setup(si, lane); }
+        else { const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)}; bin.setup(si, lane); }
         const Seg so[1] = {segd(w.G2, w.ld, O_BD, 12)};
         bout.setup(so, lane);
     }
@@ -1099,7 +1111,7 @@ SE_PASS double nlp_res_pass(double *res4)
     const double k_p1 = cls == 0 ? P.b1[cj] : P.a12[cj], k_p2 = cls == 0 ? P.b2[cj] : P.a22[cj];
     const double xh = lane >= 48 && lane < 60 ? sm.xhat[lane - 48] : 0.0;
     if (lane < NX) sm.vec[0][lane] = 0.0;
-    sweep<78, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
+    sweep<ITEMS, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
         double *cur = rg.row(k), *nxt = rg.row(k + 1);
         double *o = sm.out[k & 1];
         const double *r1 = cur, *r2 = cur + I_L;
@@ -1122,7 +1134,7 @@ SE_PASS double nlp_res_pass(double *res4)
             o[lane] = v;
         } else if (lane >= 16 && lane < 34 && res4) {
             const int j = cj;
-            const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
+            const double *pk = cur + MO_PI, *pm = sm.vec[k & 1];
             // stationarity of the NLP at the iterate (mpc_core.h stat_cls without delta), same operation order
             double v = 0.0;
             if (cls == 0) {
@@ -1154,7 +1166,7 @@ SE_PASS double nlp_res_pass(double *res4)
             const bool hc = cls == 0 ? k < N : (cls == 1 && k >= 1 && k < N);
             if (hc) {
                 const double curv = r1[ci < 6 ? O_U + ci : O_X + ci - 6];
-                const double *lam = r1 + O_QLAM, *tt = r1 + O_QT;
+                const double *lam = cur + MO_LAM, *tt = cur + MO_T;
                 if (c_lo) {
                     v -= lam[ci];
                     a_i = fmax(a_i, fabs((cb_lo - curv) + tt[ci]));
@@ -1170,7 +1182,7 @@ SE_PASS double nlp_res_pass(double *res4)
             a_s = fmax(a_s, fabs(v));
         } else if (lane >= 48 && lane < 60) {
             if (k == 0 && res4) a_i = fmax(a_i, fabs(xh - r1[O_X + lane - 48]));   // lbx_0 = ubx_0 = x_hat
-            sm.vec[(k + 1) & 1][lane - 48] = cur[O_QPI + lane - 48];
+            sm.vec[(k + 1) & 1][lane - 48] = cur[MO_PI + lane - 48];
         }
         fence();
         store_out(bout, k, o, lane);
@@ -1178,6 +1190,109 @@ SE_PASS double nlp_res_pass(double *res4)
     const double cost = wsum(csum);
     if (res4) { res4[0] = wmax(a_s); res4[1] = wmax(a_e); res4[2] = wmax(a_i); res4[3] = wmax(a_c); }
     return cost;
+}
+
+// =============================================================================================== SQP line search
+// L1 merit function at the trial point (X,U) + alpha (dX,dU) (acados ocp_nlp_evaluate_merit_fun restated;
+// mpc_core.h merit_pass).  lane <-> stage, straight from HBM.  With `update_weights` the merit weights (G5 MW) are
+// first refreshed from the QP multipliers by Leineweber's rule.
+SE_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const Robot &rb = sm.rb;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor);
+    const SWs w = sm.w;
+    double acc = 0.0;
+    for (int k0 = 0; k0 <= N; k0 += WAVE) {
+        const int k = k0 + lane;
+        if (k > N) continue;
+        MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)k * w.ld);
+        MPC_GLOBAL double *rn = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)(k < N ? k + 1 : k) * w.ld);
+        MPC_GLOBAL double *mw = (MPC_GLOBAL double *)((char *)w.G5 + (size_t)k * w.ld) + O_MW;
+        if (update_weights) {
+            for (int i = 0; i < 36; i++) {
+                const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
+                mw[i] = sqp_iter == 0 ? a : fmax(a, 0.5 * (mw[i] + a));
+            }
+        }
+        double xx[12], uu[6], rec[8];
+#pragma unroll
+        for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i] + alpha * r1[O_QW + 6 + i];
+        if (k < N) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i] + alpha * r1[O_QW + i];
+            task_lin<false>(rb, P, xx, xx + 6, rec);
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NTASK; i++) s += P.w_task[i] * rec[O_R + i] * rec[O_R + i];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const double qdd = P.cq[j] * (uu[j] - xx[6 + j]);
+                s += 2.0 * P.w_u * uu[j] * uu[j] + P.w_qddot * qdd * qdd;
+                const double xnq = rn[O_X + j] + alpha * rn[O_QW + 6 + j];
+                const double xnv = rn[O_X + 6 + j] + alpha * rn[O_QW + 12 + j];
+                acc += mw[j] * fabs((xx[j] + P.a12[j] * xx[6 + j] + P.b1[j] * uu[j]) - xnq);
+                acc += mw[6 + j] * fabs((P.a22[j] * xx[6 + j] + P.b2[j] * uu[j]) - xnv);
+                const double vl = P.umin[j] - uu[j], vu = uu[j] - P.umax[j];
+                acc += mw[12 + j] * fmax(vl, 0.0) + mw[24 + j] * fmax(vu, 0.0);
+                const double ql = P.qmin[j] - xx[j], qu = xx[j] - P.qmax[j], on = k >= 1 ? 1.0 : 0.0;
+                acc += on * (mw[18 + j] * fmax(ql, 0.0) + mw[30 + j] * fmax(qu, 0.0));
+            }
+            acc += 0.5 * P.dt * s;
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) acc += w.state[13 + i] * fabs(sm.xhat[i] - xx[i]);
+        }
+    }
+    return wsum(acc);
+}
+
+// Merit weight of the eliminated x_0 constraint: |stage-0 stationarity of the QP wrt x_0| (mpc_core.h update_x0_weights)
+SE_PASS void update_x0_weights(int sqp_iter)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const SWs w = sm.w;
+    if (lane < NX) {
+        const double *r1 = w.G1, *r2 = w.G2;      // stage 0 records (y holds W(r + G delta) of the last residual pass)
+        double v;
+        if (lane < 6) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + lane] * r2[O_Y + i];
+            v = P.dt * s + r1[O_QPI + lane] + P.dt * P.lm * r1[O_QW + 6 + lane];
+        } else {
+            const int jj = lane - 6;
+            const double uj = r1[O_U + jj] + r1[O_QW + jj], vj = r1[O_X + 6 + jj] + r1[O_QW + 12 + jj];
+            const double c2 = P.w_qddot * P.cq[jj] * P.cq[jj];
+            v = P.dt * (r2[O_GV + jj] * r2[O_Y + 4] + c2 * (vj - uj)) + P.a12[jj] * r1[O_QPI + jj] +
+                P.a22[jj] * r1[O_QPI + 6 + jj] + P.dt * P.lm * r1[O_QW + 12 + jj];
+        }
+        const double a = fabs(v);
+        double *mwp = &w.state[13 + lane];
+        *mwp = sqp_iter == 0 ? a : fmax(a, 0.5 * (*mwp + a));
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    fence();
+}
+
+// MERIT_BACKTRACKING (trajectory_optimizer.py:68; acados alpha_reduction 0.7, alpha_min 0.05)
+SE_DEV double line_search(int sqp_iter)
+{
+    update_x0_weights(sqp_iter);
+    const double m0 = unid(merit_pass(0.0, true, sqp_iter));
+    __builtin_amdgcn_s_waitcnt(0);
+    fence();
+    double alpha = 1.0;
+    while (alpha >= 0.05) {
+        if (uni(unid(merit_pass(alpha, false, sqp_iter)) < m0 ? 1 : 0)) break;
+        alpha *= 0.7;
+    }
+    return alpha;
 }
 
 // =============================================================================================== closed loop
@@ -1244,7 +1359,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         double *rd = reinterpret_cast<double *>(&sm.rb);
         for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) rd[e] = rs[e];
         if (lane == 0) {
-            SWs ws = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N);
+            SWs ws = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N, pb.solver_type == 0);
             ws.state = ws_base + (size_t)inst * ws_stride + (ws_stride - STATE_DOUBLES);   // at the end of the stride whatever this simulation's horizon
             sm.w = ws;
             sm.n_hor = N;
@@ -1259,7 +1374,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     int log_lo = step0 == 0 ? 0 : step0 + 1;
     if (step0 == 0) {
         // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0
-        const size_t tot = sws_doubles_per_instance<FT>(N) - STATE_DOUBLES;
+        const size_t tot = sws_doubles_per_instance<FT>(N, pb.solver_type == 0) - STATE_DOUBLES;
         for (size_t e = lane; e < tot; e += WAVE) w.G1[e] = 0.0;      // G1 is the workspace base
         if (lane < STATE_DOUBLES) w.state[lane] = 0.0;
         fence();
@@ -1279,27 +1394,67 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         fence();
     }
     for (int i = step0; i < step1; i++) {
-        int qp_iter = 0, status = 0;
+        int qp_iter = 0, status = 0, sqp_iter = 1;
         double res4[4] = {0, 0, 0, 0};
+        double cost = lin_cost;
         const double t0 = wclock();
-        // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
-        if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass(nullptr)); }
-        const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter);
+        if (pb.solver_type == 1) {
+            // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
+            if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass<false>(nullptr)); }
+            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter);
 #ifdef MPCB_SPROF
-        if (lane == 0) { w.state[32 + 5] += wclock() - t0; }
+            if (lane == 0) { w.state[32 + 5] += wclock() - t0; }
 #endif
-        const bool ok = qs == 0 || qs == 1;
-        if (!ok) status = 4;                                           // ACADOS_QP_FAILURE, iterate untouched
-        __builtin_amdgcn_s_waitcnt(0);
-        SPROF_T0(tl);
-        lin_pass(1.0, ok);
-        __builtin_amdgcn_s_waitcnt(0);                                 // the records written lane by lane are complete before they are streamed
-        fence();
-        SPROF_ADD(8, tl);
-        SPROF_T0(tn);
-        const double cost = unid(nlp_res_pass(res4));
-        SPROF_ADD(9, tn);
-        lin_valid = true;
+            const bool ok = qs == 0 || qs == 1;
+            if (!ok) status = 4;                                       // ACADOS_QP_FAILURE, iterate untouched
+            __builtin_amdgcn_s_waitcnt(0);
+            SPROF_T0(tl);
+            lin_pass(1.0, ok);
+            __builtin_amdgcn_s_waitcnt(0);                             // the records written lane by lane are complete before they are streamed
+            fence();
+            SPROF_ADD(8, tl);
+            SPROF_T0(tn);
+            cost = unid(nlp_res_pass<false>(res4));
+            SPROF_ADD(9, tn);
+            lin_valid = true;
+        } else {
+            // full SQP (acados ocp_nlp_sqp restated, mpc_core.h nlp_step): linearise -> residuals / convergence test -> QP ->
+            // merit backtracking -> update; sqp_iter counts QPs
+            const double tol = P.tol, tol_eq = P.tol_eq, tol_in = P.tol_ineq, tol_co = P.tol_comp;
+            status = 2;                                                // ACADOS_MAXITER unless decided otherwise
+            double alpha = 0.0;
+            bool pending = false;                                      // a step (alpha) waits to be applied by the next linearisation
+            for (sqp_iter = 0; sqp_iter < pb.max_iter; sqp_iter++) {
+                if (pending || !lin_valid || sqp_iter == 0) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    lin_pass(alpha, pending, true);
+                    __builtin_amdgcn_s_waitcnt(0);
+                    fence();
+                    cost = unid(nlp_res_pass<true>(res4));
+                    res4[0] = unid(res4[0]); res4[1] = unid(res4[1]); res4[2] = unid(res4[2]); res4[3] = unid(res4[3]);
+                    pending = false;
+                    lin_valid = true;
+                }
+                if (res4[0] < tol && res4[1] < tol_eq && res4[2] < tol_in && res4[3] < tol_co) { status = 0; break; }
+                if (res4[0] != res4[0] || cost != cost) { status = 1; break; }
+                int it = 0;
+                const int qs = ipm_solve<FT>(pb.qp_iter_max, &it);
+                qp_iter += it;
+                if (qs != 0 && qs != 1) { status = 4; break; }
+                __builtin_amdgcn_s_waitcnt(0);
+                fence();
+                alpha = pb.fixed_step ? 1.0 : line_search(sqp_iter);
+                pending = true;
+            }
+            if (pending) {   // max-iter exit: apply the last step; the residuals of the last check stay
+                __builtin_amdgcn_s_waitcnt(0);
+                lin_pass(alpha, true, true);
+                __builtin_amdgcn_s_waitcnt(0);
+                fence();
+                cost = unid(nlp_res_pass<true>(nullptr));
+                lin_valid = true;
+            }
+        }
         lin_cost = cost;
         __builtin_amdgcn_s_waitcnt(0);
         fence();
@@ -1339,7 +1494,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         }
         if (lane == 8) {
             out.status[sbase + i] = status;
-            out.sqp_iter[sbase + i] = 1;
+            out.sqp_iter[sbase + i] = sqp_iter;
             out.qp_iter[sbase + i] = qp_iter;
             out.cost[sbase + i] = cost;
             out.solver_time[sbase + i] = t1 - t0;

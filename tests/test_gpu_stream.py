@@ -60,6 +60,27 @@ def test_stream_engine_matches_oracle(stream_engine, orc, ur10, ur10_rb, N, T, B
         _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
 
 
+@pytest.mark.parametrize("N,T,B", [(10, 0.5, 3), (2, 0.1, 1), (33, 0.2, 2), (100, 0.05, 2)])
+def test_stream_engine_full_sqp_matches_oracle(stream_engine, orc, ur10, ur10_rb, N, T, B):
+    """Full SQP (merit backtracking, NLP multipliers, four tolerances) on the throughput engine."""
+    cfgs = _jitter(B, seed=100 + N, prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": "SQP"})
+    out = stream_engine.run(cfgs, ur10)
+    assert stream_engine.launch_info()["engine"] == 1
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)))
+    assert out["sqp_iter"].max() > 1
+
+
+def test_stream_engine_sqp_options(stream_engine, orc, ur10, ur10_rb):
+    cfgs = [_cfg(prediction_horizon=12, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP", "levenberg_marquardt": 1e-2}),
+            _cfg(prediction_horizon=12, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP", "tol": 1e-5, "nlp_solver_tol_stat": 1e-3}),
+            _cfg(prediction_horizon=12, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP", "globalization": "FIXED_STEP"}),
+            _cfg(prediction_horizon=12, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP", "nlp_solver_max_iter": 2})]
+    for c in cfgs:
+        out = stream_engine.run([c], ur10)
+        _check(out, 0, orc.run(ur10_rb, orc.make_params(c)))
+
+
 def test_stream_engine_bounds_parameters_integrators_lm(stream_engine, orc, ur10, ur10_rb):
     cfgs = [
         _cfg(prediction_horizon=15, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
@@ -233,3 +254,16 @@ def test_stream_engine_solver_failures_match_the_oracle(stream_engine, orc, ur10
         assert np.abs(out["qp_iter"][i] - ref["qp_iter"]).max() <= (2 if name.startswith("infeasible") else 0)
         for k in ("z", "u", "ee_pose"):
             np.testing.assert_allclose(out[k][i], ref[k], atol=1e-8, rtol=0, err_msg=f"{name} {k}")
+
+
+def test_stream_engine_ur5_and_custom_tool_offset(stream_engine, orc):
+    """Another robot (UR5 from its URDF constants) and a non-default translation_ee_t on the throughput engine."""
+    from robotic_mpc_amd import robots
+
+    ch = robots.builtin_chain("ur5")
+    cfgs = [_cfg(robot_name="ur5", prediction_horizon=12, simulation_time=0.2, q_0=np.array([0.3, -1.2, 1.4, -1.0, -1.2, 0.2]),
+                 qdot_0=np.zeros(6), px_ref=0.45, translation_ee_t=(0.01, -0.02, 0.12)) for _ in range(2)]
+    out = stream_engine.run(cfgs, ch)
+    ref = orc.run(orc.make_robot(ch, cfgs[0]["t_ee"]), orc.make_params(cfgs[0]))
+    _check(out, 0, ref)
+    _check(out, 1, ref)
