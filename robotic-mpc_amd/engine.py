@@ -160,15 +160,25 @@ class MpcBatchEngine:
         return dict(waves_per_sim=w.value, pool_bytes=pbytes.value, engine=int(self.lib.mpcb_engine(self._h)))
 
     # ------------------------------------------------------------------ device-resident path
-    def setup(self, cfgs: Sequence[Dict], chain) -> MpcbProblem:
+    @staticmethod
+    def prepare(cfgs: Sequence[Dict], chain):
+        """Resolved configs -> what mpcb_setup takes: (problem, parameter records [batch, NPARAM], robot constants [105]).
+        This is the construction-time half of Simulator.__init__ (dict -> numbers); nothing touches the device."""
         pb = make_problem(cfgs)
         params = packing.pack_batch(cfgs)
         robot = np.ascontiguousarray(chain.packed(cfgs[0]["t_ee"]), dtype=np.float64)
         assert params.shape == (len(cfgs), packing.NPARAM) and robot.shape == (105,)
+        return pb, params, robot
+
+    def setup_packed(self, pb: MpcbProblem, params: np.ndarray, robot: np.ndarray) -> MpcbProblem:
+        """mpcb_setup: validate, derive the model constants, upload the records (H2D), size the workspace."""
         self._check(self.lib.mpcb_setup(self._h, C.byref(pb), params.ctypes.data_as(_dp), robot.ctypes.data_as(_dp)),
                     "mpcb_setup")
         self._pb = pb
         return pb
+
+    def setup(self, cfgs: Sequence[Dict], chain) -> MpcbProblem:
+        return self.setup_packed(*self.prepare(cfgs, chain))
 
     def alloc_results(self, pb: MpcbProblem):
         """Device result buffers as torch tensors (dict name -> tensor [batch, ...])."""

@@ -23,8 +23,24 @@ def pack_params(cfg: Dict) -> np.ndarray:
     return p
 
 
+_SCALARS = ((0, "dt"), (1, "tol"), (2, "qp_tol"), (3, "w_u"), (4, "w_qddot"), (5, "px_ref"), (6, "vy_ref"))
+_VECTORS = ((8, "wcv", 6), (14, "q0", 6), (20, "qdot0", 6), (26, "qmin", 6), (32, "qmax", 6), (38, "umin", 6), (44, "umax", 6),
+            (50, "coeffs", 6), (56, "w_task", 5))
+_OPTIONAL = ((7, "plant_integrator"), (61, "tol_eq"), (62, "tol_ineq"), (63, "tol_comp"), (64, "levenberg_marquardt"))
+
+
 def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
-    return np.ascontiguousarray(np.stack([pack_params(c) for c in cfgs]))
+    """All instances of a launch -> [batch, NPARAM] (column-wise: one numpy conversion per field, not per simulation)."""
+    B = len(cfgs)
+    p = np.zeros((B, NPARAM), dtype=np.float64)
+    for col, key in _SCALARS:
+        p[:, col] = [c[key] for c in cfgs]
+    for col, key, n in _VECTORS:
+        p[:, col:col + n] = np.asarray([c[key] for c in cfgs], dtype=np.float64).reshape(B, n)
+    for col, key in _OPTIONAL:
+        p[:, col] = [c.get(key, 0.0) for c in cfgs]
+    p[:, 65] = [c["N"] for c in cfgs]
+    return p
 
 
 # SQP_RTI buckets that differ only in the prediction horizon are merged into one RAGGED launch of the throughput engine
