@@ -263,6 +263,12 @@ SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
     for (int j = 0; j <= D; j++)
         if (j <= N) dma_issue(bin, row(j), rg.row(row(j)));
     if (N + 1 <= D) wait_vm<0>();                            // short horizon: everything was issued above
+    // ring slots of the row in work, the next and the previous row of the sweep, and the row to fetch: stepped, not
+    // recomputed (k % slots is a multiply-high sequence on the scalar unit, several times per stage)
+    constexpr int STEP = BACK ? SLOTS - 1 : 1;               // +1 forward, -1 backward (mod SLOTS)
+    int s_cur = row(0) % SLOTS;
+    int s_nxt = (s_cur + STEP) % SLOTS, s_prv = (s_cur + SLOTS - STEP) % SLOTS;
+    int s_dma = row(N + 1 > D ? D + 1 : 0) % SLOTS;          // slot of row(i + 1 + D) at i = 0
     for (int i = 0; i <= N; i++) {
         if (N + 1 > D) {
             if (i + 1 > N) wait_vm<0>();
@@ -271,8 +277,11 @@ SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
             else wait_vm<W_STEADY>();
         }
         fence();
-        body(row(i), rg);
-        if (i + 1 + D <= N) dma_issue(bin, row(i + 1 + D), rg.row(row(i + 1 + D)));
+        body(row(i), g_ssm.ring + s_cur * SLOT, g_ssm.ring + s_nxt * SLOT, g_ssm.ring + s_prv * SLOT);
+        if (i + 1 + D <= N) dma_issue(bin, row(i + 1 + D), g_ssm.ring + s_dma * SLOT);
+        s_prv = s_cur; s_cur = s_nxt;
+        s_nxt = s_nxt + STEP; s_nxt = s_nxt >= SLOTS ? s_nxt - SLOTS : s_nxt;
+        s_dma = s_dma + STEP; s_dma = s_dma >= SLOTS ? s_dma - SLOTS : s_dma;
     }
 }
 
@@ -387,8 +396,7 @@ SE_PASS IpmNorms residual_pass(double a)
         }
     };
     if (lane < NX) sm.vec[0][lane] = 0.0;      // pi_{-1}: never read (k = 0 rows return early)
-    sweep<117, 2, false>(bin, N, lane, [&](int k, const Ring &rg) {
-        double *cur = rg.row(k), *nxt = rg.row(k + 1);
+    sweep<117, 2, false>(bin, N, lane, [&](int k, double *cur, double *nxt, double *) {
         double *o = sm.out[k & 1];
 #ifdef MPCB_NOCOMPUTE
         (void)cur; (void)nxt; store_out(bout, k, o, lane); return;
@@ -584,9 +592,9 @@ SE_PASS void fact_pass()
         f.qvq = cq;
         f.qvv = cq * f.a12b + cv * f.a22b;
     };
-    sweep<39, NIO, true>(bin, N, lane, [&](int k, const Ring &rg) {
-        const double *ric = rg.row(k);
-        const double *ricd = rg.row(k > 0 ? k - 1 : 0);           // row k-1 (valid for k >= 1)
+    sweep<39, NIO, true>(bin, N, lane, [&](int k, double *ric_, double *ricd_, double *) {
+        const double *ric = ric_;
+        const double *ricd = ricd_;                               // row k-1: the next row of this backward sweep (valid for k >= 1)
         MPC_LOCAL FT *fac = (MPC_LOCAL FT *)sm.out[k & 1];
         const MPC_LOCAL FT *facn = (const MPC_LOCAL FT *)sm.out[(k + 1) & 1];   // row k+1 (valid for k < N)
 #ifdef MPCB_NOCOMPUTE
@@ -773,8 +781,8 @@ SE_PASS StepInfo forward_pass()
     const int jl = lane >= 48 && lane < 60 ? lane - 48 : 0;        // lagging role: bounded component
     const bool jl_lo = bnd_lo(P, jl) > -BOUND_INF, jl_hi = bnd_hi(P, jl) < BOUND_INF;
     if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
-    auto stage = [&](int k, const Ring &rg) {
-        const double *row = rg.row(k), *rowp = rg.row(k > 0 ? k - 1 : 0);
+    auto stage = [&](int k, double *row_, double *, double *rowp_) {
+        const double *row = row_, *rowp = rowp_;                   // rowp: row k-1, the previous row of this forward sweep
         const MPC_LOCAL FT *fac = (const MPC_LOCAL FT *)row;
         double *o = sm.out[k & 1], *op = sm.out[(k + 1) & 1];
 #ifdef MPCB_NOCOMPUTE
@@ -841,7 +849,10 @@ SE_PASS StepInfo forward_pass()
     };
     sweep<ITEMS, 1, false>(bin, N, lane, stage);
     fence();
-    stage(N + 1, make_ring<ITEMS>());      // the lagging role's last stage
+    {   // the lagging role's last stage: "row N+1" does not exist, its predecessor is row N
+        const Ring rg = make_ring<ITEMS>();
+        stage(N + 1, rg.row(N + 1), nullptr, rg.row(N));
+    }
     StepInfo s;
     s.alpha = wmin(al); s.S0 = wsum(a0); s.S1 = wsum(a1); s.S2 = wsum(a2);
     return s;
@@ -901,8 +912,8 @@ SE_PASS void corrector_pass(double sigma_mu)
         if (j < 6) og[12 + j] = gtb[12 + j];
         rmo[j] = rml; rmo[12 + j] = rmu;
     };
-    sweep<ITEMS, 1, true>(bin, N, lane, [&](int k, const Ring &rg) {
-        const double *row = rg.row(k), *rowd = rg.row(k > 0 ? k - 1 : 0);
+    sweep<ITEMS, 1, true>(bin, N, lane, [&](int k, double *row_, double *rowd_, double *) {
+        const double *row = row_, *rowd = rowd_;                   // rowd: row k-1, the next row of this backward sweep
         if (k == N) {
             if (lane >= 32 && lane < 44) corr_row(row, N, lane - 32);
             fence();
@@ -1111,8 +1122,7 @@ SE_PASS double nlp_res_pass(double *res4)
     const double k_p1 = cls == 0 ? P.b1[cj] : P.a12[cj], k_p2 = cls == 0 ? P.b2[cj] : P.a22[cj];
     const double xh = lane >= 48 && lane < 60 ? sm.xhat[lane - 48] : 0.0;
     if (lane < NX) sm.vec[0][lane] = 0.0;
-    sweep<ITEMS, 1, false>(bin, N, lane, [&](int k, const Ring &rg) {
-        double *cur = rg.row(k), *nxt = rg.row(k + 1);
+    sweep<ITEMS, 1, false>(bin, N, lane, [&](int k, double *cur, double *nxt, double *) {
         double *o = sm.out[k & 1];
         const double *r1 = cur, *r2 = cur + I_L;
         if (lane < 12) {
