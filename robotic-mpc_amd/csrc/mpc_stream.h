@@ -167,6 +167,16 @@ template <int NI>
 struct Bundle {
     MPC_GLOBAL char *g[NI];   // this lane's item in row 0 (nullptr: lane idle in this instruction)
     int stride[NI];           // bytes per row
+    MPC_GLOBAL char *p[NI];   // running pointer: this lane's item in the next row to be copied (a sweep visits consecutive
+    int step[NI];             // rows: one 64-bit add per copy instead of a 64-bit multiply-add, which runs at quarter rate)
+    SE_DEV void seek(int k, int dir)
+    {
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            p[j] = g[j] ? g[j] + (long long)k * stride[j] : nullptr;
+            step[j] = dir * stride[j];
+        }
+    }
     template <int NS>
     SE_DEV void setup(const Seg (&s)[NS], int lane)
     {
@@ -191,27 +201,30 @@ struct Bundle {
 // Asynchronous fetch of row k of a bundle straight into LDS (global_load_lds_dwordx4: no VGPR destination, the data
 // land at slot + j KiB + lane * 16 B; completion is visible only through vmcnt).
 template <int NI>
-SE_DEV void dma_issue(const Bundle<NI> &b, int k, double *slot)
+SE_DEV void dma_issue(Bundle<NI> &b, double *slot)
 {
 #pragma unroll
-    for (int j = 0; j < NI; j++)
+    for (int j = 0; j < NI; j++) {
 #ifndef MPCB_NODMA
         if (b.g[j])
-            __builtin_amdgcn_global_load_lds((const MPC_GLOBAL void *)(b.g[j] + (long long)k * b.stride[j]),
-                                             (MPC_LOCAL void *)(slot + j * 2 * WAVE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const MPC_GLOBAL void *)b.p[j], (MPC_LOCAL void *)(slot + j * 2 * WAVE), 16, 0, 0);
 #else
-        (void)k, (void)slot;
+        (void)slot;
 #endif
+        b.p[j] += b.step[j];
+    }
 }
+// stores the NEXT row of the bundle's sweep (seek() names the first one and the direction)
 template <int NI>
-SE_DEV void store_out(const Bundle<NI> &b, int k, const double *lds, int lane)
+SE_DEV void store_out(Bundle<NI> &b, const double *lds, int lane)
 {
 #pragma unroll
     for (int j = 0; j < NI; j++)
     {
 #ifndef MPCB_NOSTORE
-        if (b.g[j]) *(MPC_GLOBAL D2 *)(b.g[j] + (long long)k * b.stride[j]) = ((const MPC_LOCAL D2 *)lds)[j * WAVE + lane];
+        if (b.g[j]) *(MPC_GLOBAL D2 *)b.p[j] = ((const MPC_LOCAL D2 *)lds)[j * WAVE + lane];
 #endif
+        b.p[j] += b.step[j];
     }
 }
 constexpr int ni_of(int bytes) { return (bytes / 16 + WAVE - 1) / WAVE; }
@@ -245,7 +258,7 @@ SE_DEV Ring make_ring()
     return rg;
 }
 template <int ITEMS, int NO, bool BACK, int NI, class F>
-SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
+SE_DEV void sweep(Bundle<NI> &bin, int N, int lane, F &&body)
 {
     static_assert((ITEMS + WAVE - 1) / WAVE == NI, "bundle size and copy instruction count disagree");
     constexpr int SLOT = ITEMS * 2;                          // doubles
@@ -260,8 +273,9 @@ SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
     (void)lane;
     wait_vm<0>();                                            // nothing of an earlier pass is in flight
     fence();
+    bin.seek(row(0), BACK ? -1 : 1);
     for (int j = 0; j <= D; j++)
-        if (j <= N) dma_issue(bin, row(j), rg.row(row(j)));
+        if (j <= N) dma_issue(bin, rg.row(row(j)));
     if (N + 1 <= D) wait_vm<0>();                            // short horizon: everything was issued above
     // ring slots of the row in work, the next and the previous row of the sweep, and the row to fetch: stepped, not
     // recomputed (k % slots is a multiply-high sequence on the scalar unit, several times per stage)
@@ -278,7 +292,7 @@ SE_DEV void sweep(const Bundle<NI> &bin, int N, int lane, F &&body)
         }
         fence();
         body(row(i), g_ssm.ring + s_cur * SLOT, g_ssm.ring + s_nxt * SLOT, g_ssm.ring + s_prv * SLOT);
-        if (i + 1 + D <= N) dma_issue(bin, row(i + 1 + D), g_ssm.ring + s_dma * SLOT);
+        if (i + 1 + D <= N) dma_issue(bin, g_ssm.ring + s_dma * SLOT);
         s_prv = s_cur; s_cur = s_nxt;
         s_nxt = s_nxt + STEP; s_nxt = s_nxt >= SLOTS ? s_nxt - SLOTS : s_nxt;
         s_dma = s_dma + STEP; s_dma = s_dma >= SLOTS ? s_dma - SLOTS : s_dma;
@@ -352,6 +366,7 @@ SE_PASS IpmNorms residual_pass(double a)
         bin.setup(si, lane);
         const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, 10), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)};
         bout.setup(so, lane);
+        bout.seek(0, 1);
     }
     double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0, ncl = 0;
     // Everything a lane needs of the parameters sits in its registers for the whole sweep (LDS reads of the parameter
@@ -399,7 +414,7 @@ SE_PASS IpmNorms residual_pass(double a)
     sweep<117, 2, false>(bin, N, lane, [&](int k, double *cur, double *nxt, double *) {
         double *o = sm.out[k & 1];
 #ifdef MPCB_NOCOMPUTE
-        (void)cur; (void)nxt; store_out(bout, k, o, lane); return;
+        (void)cur; (void)nxt; store_out(bout, o, lane); return;
 #endif
         if (k == 0) { upd_row(cur, 0); fence(); }
         // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
@@ -511,7 +526,7 @@ SE_PASS IpmNorms residual_pass(double a)
             }
         }
         fence();
-        store_out(bout, k, o, lane);
+        store_out(bout, o, lane);
     });
     IpmNorms r;
     r.ng = wmax(a_g); r.nb = wmax(a_b); r.nd = wmax(a_d); r.nm = wmax(a_m); r.smu = wsum(a_mu); r.nc = wsum(ncl);
@@ -549,6 +564,7 @@ SE_PASS void fact_pass()
         bin.setup(si, lane);
         const Seg so[1] = {segf<FT>(w.G4, w.ld, 0, SW4)};
         bout.setup(so, lane);
+        bout.seek(N, -1);
     }
     FactLane<FT> f;
     {
@@ -598,7 +614,7 @@ SE_PASS void fact_pass()
         MPC_LOCAL FT *fac = (MPC_LOCAL FT *)sm.out[k & 1];
         const MPC_LOCAL FT *facn = (const MPC_LOCAL FT *)sm.out[(k + 1) & 1];   // row k+1 (valid for k < N)
 #ifdef MPCB_NOCOMPUTE
-        (void)ric; (void)ricd; (void)fac; (void)facn; store_out(bout, k, sm.out[k & 1], lane); return;
+        (void)ric; (void)ricd; (void)fac; (void)facn; store_out(bout, sm.out[k & 1], lane); return;
 #endif
         const double *gam = ric + 36, *gt = ric + 48, *rbv = ric + 66;
         if (k == N) {
@@ -616,7 +632,7 @@ SE_PASS void fact_pass()
                 sm.vec[0][jv] = (double)pr;
             }
             fence();
-            store_out(bout, k, sm.out[k & 1], lane);
+            store_out(bout, sm.out[k & 1], lane);
             return;
         }
         // ---- B: LDL' (right-looking, redundant in every lane) + one right-hand side per lane ; vector lanes: t
@@ -737,7 +753,7 @@ SE_PASS void fact_pass()
         }
         sb ^= 1;
         fence();
-        store_out(bout, k, sm.out[k & 1], lane);
+        store_out(bout, sm.out[k & 1], lane);
     });
 }
 
@@ -770,6 +786,7 @@ SE_PASS StepInfo forward_pass()
         bin.setup(si, lane);
         if (AFFINE) { const Seg so[1] = {segd(w.G3, w.ld, O_DLAM, 48)}; bout.setup(so, lane); }
         else { const Seg so[1] = {segd(w.G3, w.ld, O_DW, 78)}; bout.setup(so, lane); }
+        bout.seek(0, 1);                                           // (stage k stores row k-1, starting with row 0)
     }
     const int j12 = lane & 15;                                     // component of the 12-lane roles
     const int j6 = j12 % 6;
@@ -786,7 +803,7 @@ SE_PASS StepInfo forward_pass()
         const MPC_LOCAL FT *fac = (const MPC_LOCAL FT *)row;
         double *o = sm.out[k & 1], *op = sm.out[(k + 1) & 1];
 #ifdef MPCB_NOCOMPUTE
-        (void)row; (void)rowp; (void)fac; (void)o; if (k >= 1) store_out(bout, k - 1, AFFINE ? op + 30 : op, lane); return;
+        (void)row; (void)rowp; (void)fac; (void)o; if (k >= 1) store_out(bout, AFFINE ? op + 30 : op, lane); return;
 #endif
         const double *dxk = sm.vec[k & 1];
         if (lane < 12 && k <= N) {
@@ -845,7 +862,7 @@ SE_PASS StepInfo forward_pass()
             op[54 + j] = dtl; op[66 + j] = dtu;
         }
         fence();
-        if (k >= 1) store_out(bout, k - 1, AFFINE ? op + 30 : op, lane);
+        if (k >= 1) store_out(bout, AFFINE ? op + 30 : op, lane);
     };
     sweep<ITEMS, 1, false>(bin, N, lane, stage);
     fence();
@@ -885,6 +902,7 @@ SE_PASS void corrector_pass(double sigma_mu)
         bin.setup(si, lane);
         const Seg so[2] = {segd(w.G3, w.ld, O_RM, 24), segf<FT>(w.G4, w.ld, SVH, 32)};
         bout.setup(so, lane);
+        bout.seek(N, -1);
         (void)OB;
     }
     const int j12 = lane & 15, j6 = j12 % 6;
@@ -919,7 +937,7 @@ SE_PASS void corrector_pass(double sigma_mu)
             fence();
         }
 #ifdef MPCB_NOCOMPUTE
-        (void)rowd; store_out(bout, k, sm.out[k & 1], lane); return;
+        (void)rowd; store_out(bout, sm.out[k & 1], lane); return;
 #endif
         const double *gtc = sm.gtc[k & 1], *gtb = row + I_GB;
         const MPC_LOCAL FT *kf = (const MPC_LOCAL FT *)(row + I_F), *wv = kf + 72, *ri = kf + 84;
@@ -965,7 +983,7 @@ SE_PASS void corrector_pass(double sigma_mu)
             ofac[6 + (lane - 28)] = (FT)0;
         }
         fence();
-        store_out(bout, k, o, lane);
+        store_out(bout, o, lane);
     });
 }
 
@@ -1109,6 +1127,7 @@ SE_PASS double nlp_res_pass(double *res4)
         else { const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)}; bin.setup(si, lane); }
         const Seg so[1] = {segd(w.G2, w.ld, O_BD, 12)};
         bout.setup(so, lane);
+        bout.seek(0, 1);
     }
     double csum = 0.0, a_s = 0, a_e = 0, a_i = 0, a_c = 0;
     // per-lane parameters in registers for the whole sweep (see residual_pass)
@@ -1195,7 +1214,7 @@ SE_PASS double nlp_res_pass(double *res4)
             sm.vec[(k + 1) & 1][lane - 48] = cur[MO_PI + lane - 48];
         }
         fence();
-        store_out(bout, k, o, lane);
+        store_out(bout, o, lane);
     });
     const double cost = wsum(csum);
     if (res4) { res4[0] = wmax(a_s); res4[1] = wmax(a_e); res4[2] = wmax(a_i); res4[3] = wmax(a_c); }
