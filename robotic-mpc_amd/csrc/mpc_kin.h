@@ -86,8 +86,10 @@ MPC_HD void kin_eval(const Robot &rb, const double *q, Kin &k)
 // Task functions g1..g5 minus their references (trajectory_optimizer.py:109-126), and, when
 // JAC, the Jacobian rows wrt q (5x6) and d g5 / d qdot (6).  Output goes straight into a G2
 // (LINR) stage record: rec[O_R..] = r, rec[O_GQ..] = Gq, rec[O_GV..] = gv5.
+// rec_r receives r, rec_g the Jacobian entries (the same record for both, or r kept in registers while the
+// Jacobian goes straight to memory).
 template <bool JAC>
-MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *rec)
+MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *rec_r, double *rec_g)
 {
     Kin k;
     kin_eval(rb, q, k);
@@ -110,11 +112,11 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         om = om + qd[j] * k.z[j];
     }
     const V3 s = vl + cross(om, tw);
-    rec[O_R + 0] = (S - pt.z) - 0.0;
-    rec[O_R + 1] = dot(n, zh) - 1.0;
-    rec[O_R + 2] = yh.x - 0.0;
-    rec[O_R + 3] = pt.x - P.px_ref;
-    rec[O_R + 4] = dot(yh, s) - P.vy_ref;  // v_task,y = (R^T (v + w x t_w))_y, prediction_model.py:313
+    rec_r[O_R + 0] = (S - pt.z) - 0.0;
+    rec_r[O_R + 1] = dot(n, zh) - 1.0;
+    rec_r[O_R + 2] = yh.x - 0.0;
+    rec_r[O_R + 3] = pt.x - P.px_ref;
+    rec_r[O_R + 4] = dot(yh, s) - P.vy_ref;  // v_task,y = (R^T (v + w x t_w))_y, prediction_model.py:313
     if (!JAC) return;
     const V3 mX = v3(2 * a, c, 0), mY = v3(c, 2 * b, 0);
     const double pX = dot(n, mX), pY = dot(n, mY);
@@ -124,11 +126,11 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         const V3 zi = k.z[i];
         const V3 dpt = cross(zi, pt - k.o[i]);
         const V3 dzh = cross(zi, zh), dyh = cross(zi, yh), dtw = cross(zi, tw);
-        rec[O_GQ + 0 * 6 + i] = Sx * dpt.x + Sy * dpt.y - dpt.z;
+        rec_g[O_GQ + 0 * 6 + i] = Sx * dpt.x + Sy * dpt.y - dpt.z;
         const V3 dn = dpt.x * nX + dpt.y * nY;
-        rec[O_GQ + 1 * 6 + i] = dot(dn, zh) + dot(n, dzh);
-        rec[O_GQ + 2 * 6 + i] = dyh.x;
-        rec[O_GQ + 3 * 6 + i] = dpt.x;
+        rec_g[O_GQ + 1 * 6 + i] = dot(dn, zh) + dot(n, dzh);
+        rec_g[O_GQ + 2 * 6 + i] = dyh.x;
+        rec_g[O_GQ + 3 * 6 + i] = dpt.x;
         V3 dvl = v3(0, 0, 0), otail = v3(0, 0, 0);
 #pragma unroll
         for (int j = i + 1; j < 6; j++) {
@@ -139,9 +141,15 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         }
         const V3 dom = cross(zi, otail);
         const V3 ds = dvl + cross(dom, tw) + cross(om, dtw);
-        rec[O_GQ + 4 * 6 + i] = dot(dyh, s) + dot(yh, ds);
-        rec[O_GV + i] = dot(yh, cj[i] + cross(zi, tw));
+        rec_g[O_GQ + 4 * 6 + i] = dot(dyh, s) + dot(yh, ds);
+        rec_g[O_GV + i] = dot(yh, cj[i] + cross(zi, tw));
     }
+}
+
+template <bool JAC>
+MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *rec)
+{
+    task_lin<JAC>(rb, P, q, qd, rec, rec);
 }
 
 // Plant log (simulation_model.py:60-77): pose = [p; R row-major], rpy, J_world * qdot.

@@ -1087,15 +1087,13 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
                 for (int i = 0; i < 60; i++) r5[i] += alpha * (r1[O_QPI + i] - r5[i]);   // NPI | NLAM | NT <- QPI | QLAM | QT
             }
         }
-        double rec[W2_LIN];
         if (k < N) {
-            task_lin<true>(rb, P, xx, xx + 6, rec);
+            double rl[10];                                             // r | Y; the Jacobian goes straight to the record
+            task_lin<true>(rb, P, xx, xx + 6, rl, (double *)r2);
 #pragma unroll
-            for (int i = 0; i < NTASK; i++) rec[O_Y + i] = P.w_task[i] * rec[O_R + i];
+            for (int i = 0; i < NTASK; i++) rl[O_Y + i] = P.w_task[i] * rl[O_R + i];
 #pragma unroll
-            for (int i = 0; i < 10; i++) r2[i] = rec[i];
-#pragma unroll
-            for (int i = O_GQ; i < W2_LIN; i++) r2[i] = rec[i];
+            for (int i = 0; i < 10; i++) r2[i] = rl[i];
         } else {
 #pragma unroll
             for (int i = 0; i < 10; i++) r2[i] = 0.0;
