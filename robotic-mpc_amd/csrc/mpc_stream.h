@@ -163,8 +163,12 @@ SE_DEV Seg segd(double *base, int ld_bytes, int c0, int w) { Seg s; s.base = (ch
 template <class FT>
 SE_DEV Seg segf(char *base, int ld_bytes, int c0, int w) { Seg s; s.base = base; s.ld = ld_bytes; s.off = c0 * (int)sizeof(FT); s.w = w * (int)sizeof(FT); return s; }
 
-template <int NI>
+// ITEMS (when given): the bundle's number of 16-byte items -- copy instructions that are full (every lane busy) then
+// need no exec mask (a v_cmp / s_and_saveexec / s_cbranch / s_or sequence per instruction and stage otherwise).
+template <int NI, int ITEMS = 0>
 struct Bundle {
+    static_assert(ITEMS == 0 || (ITEMS + WAVE - 1) / WAVE == NI, "bundle size and copy instruction count disagree");
+    static constexpr bool full(int j) { return ITEMS > 0 && (j + 1) * WAVE <= ITEMS; }
     MPC_GLOBAL char *g[NI];   // this lane's item in row 0 (nullptr: lane idle in this instruction)
     int stride[NI];           // bytes per row
     MPC_GLOBAL char *p[NI];   // running pointer: this lane's item in the next row to be copied (a sweep visits consecutive
@@ -200,13 +204,13 @@ struct Bundle {
 };
 // Asynchronous fetch of row k of a bundle straight into LDS (global_load_lds_dwordx4: no VGPR destination, the data
 // land at slot + j KiB + lane * 16 B; completion is visible only through vmcnt).
-template <int NI>
-SE_DEV void dma_issue(Bundle<NI> &b, double *slot)
+template <int NI, int BI>
+SE_DEV void dma_issue(Bundle<NI, BI> &b, double *slot)
 {
 #pragma unroll
     for (int j = 0; j < NI; j++) {
 #ifndef MPCB_NODMA
-        if (b.g[j])
+        if (Bundle<NI, BI>::full(j) || b.g[j])
             __builtin_amdgcn_global_load_lds((const MPC_GLOBAL void *)b.p[j], (MPC_LOCAL void *)(slot + j * 2 * WAVE), 16, 0, 0);
 #else
         (void)slot;
@@ -215,14 +219,14 @@ SE_DEV void dma_issue(Bundle<NI> &b, double *slot)
     }
 }
 // stores the NEXT row of the bundle's sweep (seek() names the first one and the direction)
-template <int NI>
-SE_DEV void store_out(Bundle<NI> &b, const double *lds, int lane)
+template <int NI, int BI>
+SE_DEV void store_out(Bundle<NI, BI> &b, const double *lds, int lane)
 {
 #pragma unroll
     for (int j = 0; j < NI; j++)
     {
 #ifndef MPCB_NOSTORE
-        if (b.g[j]) *(MPC_GLOBAL D2 *)b.p[j] = ((const MPC_LOCAL D2 *)lds)[j * WAVE + lane];
+        if (Bundle<NI, BI>::full(j) || b.g[j]) *(MPC_GLOBAL D2 *)b.p[j] = ((const MPC_LOCAL D2 *)lds)[j * WAVE + lane];
 #endif
         b.p[j] += b.step[j];
     }
@@ -257,10 +261,10 @@ SE_DEV Ring make_ring()
     rg.slots = RING_DOUBLES / rg.slot_doubles > 12 ? 12 : RING_DOUBLES / rg.slot_doubles;
     return rg;
 }
-template <int ITEMS, int NO, bool BACK, int NI, class F>
-SE_DEV void sweep(Bundle<NI> &bin, int N, int lane, F &&body)
+template <int ITEMS, int NO, bool BACK, int NI, int BI, class F>
+SE_DEV void sweep(Bundle<NI, BI> &bin, int N, int lane, F &&body)
 {
-    static_assert((ITEMS + WAVE - 1) / WAVE == NI, "bundle size and copy instruction count disagree");
+    static_assert((ITEMS + WAVE - 1) / WAVE == NI && (BI == 0 || BI == ITEMS), "bundle size and copy instruction count disagree");
     constexpr int SLOT = ITEMS * 2;                          // doubles
     constexpr int SLOTS = RING_DOUBLES / SLOT > 12 ? 12 : RING_DOUBLES / SLOT;
     constexpr int D = SLOTS - 2;
@@ -360,7 +364,8 @@ SE_PASS IpmNorms residual_pass(double a)
     const SWs w = sm.w;
     constexpr int I_D = 96, I_L = 174;                       // input image: G1 row | D | lin
     constexpr int O_W = 0, O_RY = 78, O_G = 88, O_3 = 130;   // output image
-    Bundle<2> bin, bout;
+    Bundle<2, 117> bin;
+    Bundle<2, 98> bout;
     {
         const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G3, w.ld, O_DW, 78), segd(w.G2, w.ld, 0, W2_LIN)};
         bin.setup(si, lane);
@@ -557,8 +562,8 @@ SE_PASS void fact_pass()
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
     constexpr int NIO = ni_of(SW4 * (int)sizeof(FT));
-    Bundle<1> bin;
-    Bundle<NIO> bout;
+    Bundle<1, 39> bin;
+    Bundle<NIO, SW4 * (int)sizeof(FT) / 16> bout;
     {
         const Seg si[1] = {segd(w.G2, w.ld, O_GQ, 78)};
         bin.setup(si, lane);
@@ -779,8 +784,8 @@ SE_PASS StepInfo forward_pass()
     constexpr int ITEMS = (FB + 96 * 8) / 16;
     constexpr int NII = ni_of(FB + 96 * 8);
     constexpr int I_LT = FB / 8, I_R = I_LT + 48;                  // doubles
-    Bundle<NII> bin;
-    Bundle<1> bout;
+    Bundle<NII, ITEMS> bin;
+    Bundle<1, AFFINE ? 24 : 39> bout;
     {
         const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)};
         bin.setup(si, lane);
@@ -894,8 +899,8 @@ SE_PASS void corrector_pass(double sigma_mu)
     constexpr int ITEMS = (168 * 8 + FBYTES) / 16;
     constexpr int NII = ni_of(168 * 8 + FBYTES);
     constexpr int OB = 24 * 8 + 32 * (int)sizeof(FT);
-    Bundle<NII> bin;
-    Bundle<1> bout;
+    Bundle<NII, ITEMS> bin;
+    Bundle<1, OB / 16> bout;
     {
         const Seg si[6] = {segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, 0, 42), segd(w.G3, w.ld, O_DLAM, 48), segd(w.G2, w.ld, O_GT, 30),
                            segf<FT>(w.G4, w.ld, SK, 72), segf<FT>(w.G4, w.ld, SWV, 48)};
@@ -1118,8 +1123,8 @@ SE_PASS double nlp_res_pass(double *res4)
     constexpr int I_L = 96, I_5 = 156;
     constexpr int ITEMS = SQPM ? 108 : 78;
     constexpr int MO_PI = SQPM ? I_5 + O_NPI : O_QPI, MO_LAM = SQPM ? I_5 + O_NLAM : O_QLAM, MO_T = SQPM ? I_5 + O_NT : O_QT;
-    Bundle<2> bin;
-    Bundle<1> bout;
+    Bundle<2, ITEMS> bin;
+    Bundle<1, 6> bout;
     {
         if (SQPM) { const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN), segd(w.G5, w.ld, 0, 60)}; bin.setup(si, lane); }
         else { const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)}; bin.setup(si, lane); }
