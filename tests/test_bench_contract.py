@@ -1,0 +1,54 @@
+"""The driver's bench.py contract (one JSON line with the fields the round prompt names), run end to end on the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _run_bench(*flags):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_baseline_names_the_bench_workload():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    sys.path.insert(0, ROOT)
+    import bench
+    cfgs = bench.workload_configs(4, 100, 6.0, seed=0, solver="SQP_RTI")
+    assert "N=100" in base["metric"] and "dt=0.01" in base["metric"]
+    assert len(cfgs) == 4 and all(c["N"] == 100 and c["Nsim"] == 600 and abs(c["dt"] - 0.01) < 1e-15 for c in cfgs)
+    assert bench.bytes_per_mpc_step(100) == 8 * (108 * 100 + 95)
+
+
+@pytest.mark.gpu
+def test_bench_line_on_a_small_workload():
+    # a reduced workload (the contract, not the number): 64 simulations, 60 closed-loop steps
+    r = _run_bench("--steps", "2", "--warmup", "1", "--batch", "64", "--sim-time", "0.6")
+    for k in REQUIRED:
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["dtype"] == "f64" and r["scaling"] == "weak" and r["vs_baseline"] is None and "synthetic" in r["data"]
+    assert "workload" in r["config"] and "model" not in r["config"]
+    # value = whole-job MPC steps / timed seconds
+    steps_per_pass = 64 * 60
+    assert abs(r["value"] - steps_per_pass / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["avg_launch_ms"] <= r["ms_per_step"] + 1e-6       # the kernel is inside the timed region
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * rf["achieved"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert r["config"]["solver_failures"] == 0
