@@ -228,7 +228,9 @@ def main():
         local = dict(bufs)
         local["summary"] = eng.summary(bufs)
         if world > 1:
-            return dmod.gather_to_root(local, sizes)          # product path of run_all: device tensors -> RCCL -> one D2H
+            out = dmod.gather_to_root(local, sizes)           # product path of run_all: device tensors -> RCCL -> one D2H
+            torch.cuda.current_stream().synchronize()         # a pass ends when this rank's results have left its buffers
+            return out
         return {k: dmod.to_host(v) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
 
     for _ in range(args.warmup):
@@ -238,6 +240,7 @@ def main():
     host = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        host = None                        # (frees the previous pass's pinned arrays before the next ones are taken)
         host = one_pass()
         kernel_ms.append(eng.kernel_ms())  # HIP events on the launch stream (the pass has already waited for the kernel,
     barrier()                              # except with --kernel-only, where this wait is the only sync)

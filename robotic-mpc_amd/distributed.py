@@ -104,11 +104,13 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
     """The one exchange step of a sharded run: gather per-rank arrays [n_r, ...] (n_r = sizes[r]) to rank 0.
 
     ``local`` holds torch tensors (device tensors from the engine) or numpy arrays.  With the ``nccl`` backend
-    (RCCL over xGMI) the DEVICE tensors go into ``dist.gather`` as they are -- no host hop before the collective --
-    and rank 0 copies the gathered tensors to the host once.  With ``gloo`` (CPU rehearsal) tensors are moved to
-    the host first.  The collective is chosen by the backend alone (``dist.gather`` exists for both), never per
-    rank or per exception: ranks that disagree on the collective would deadlock.  Shards are padded to
-    max(sizes) because gather needs equal shapes."""
+    (RCCL over xGMI) the DEVICE tensors go into ``dist.gather`` as they are -- no host hop before the collective.
+    Rank 0 receives every array into ONE contiguous device buffer [world * max(sizes), ...] (the gather's output list
+    are views of it), so the result needs no concatenation on the host, and copies it to pinned host memory on a
+    side stream while the next array is being gathered; one wait at the end.  With ``gloo`` (CPU rehearsal) tensors
+    are moved to the host first and the gathered buffer IS the result.  The collective is chosen by the backend alone
+    (``dist.gather`` exists for both), never per rank or per exception: ranks that disagree on the collective would
+    deadlock.  Shards are padded to max(sizes) because gather needs equal shapes; the padding rows are cut on rank 0."""
     import torch
     import torch.distributed as dist
 
@@ -116,7 +118,9 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
     on_device = dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_device()) if on_device else torch.device("cpu")
     nmax = max(sizes)
-    out: Dict[str, np.ndarray] = {}
+    uniform = all(n == nmax for n in sizes)
+    copy_stream = torch.cuda.Stream(device=dev) if on_device and me == 0 else None
+    gathered: Dict[str, "torch.Tensor"] = {}
     for name in sorted(local):
         a = local[name]
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
@@ -126,11 +130,31 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
             pad = torch.zeros((nmax - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
             t = torch.cat([t, pad], dim=0)
         t = t.contiguous()
-        bufs = [torch.empty_like(t) for _ in range(ws)] if me == 0 else None
-        dist.gather(t, bufs, dst=0)
-        if me == 0:
-            out[name] = np.concatenate([to_host(b[: sizes[r]]) for r, b in enumerate(bufs)], axis=0)
-    return out if me == 0 else None
+        big = torch.empty((ws * nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) if me == 0 else None
+        dist.gather(t, list(big.split(nmax, dim=0)) if me == 0 else None, dst=0)
+        if me != 0:
+            continue
+        if not on_device:
+            gathered[name] = big
+            continue
+        # (dist.gather has made the current stream wait for the collective: an event recorded now covers it)
+        done = torch.cuda.Event()
+        done.record()
+        host = torch.empty(big.shape, dtype=big.dtype, pin_memory=True)
+        copy_stream.wait_event(done)
+        with torch.cuda.stream(copy_stream):
+            host.copy_(big, non_blocking=True)
+        big.record_stream(copy_stream)       # the allocator must not hand `big` out again before the copy has run
+        gathered[name] = host
+    if me != 0:
+        return None
+    if copy_stream is not None:
+        copy_stream.synchronize()
+    out: Dict[str, np.ndarray] = {}
+    for name, h in gathered.items():
+        arr = h.numpy()
+        out[name] = arr if uniform else np.concatenate([arr[r * nmax: r * nmax + sizes[r]] for r in range(ws)], axis=0)
+    return out
 
 
 def to_host(v) -> np.ndarray:
@@ -188,7 +212,7 @@ def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Calla
         if local is not None and "_kernel_ms" in local:
             kernel_ms += float(local.pop("_kernel_ms"))
         t0 = time.perf_counter()
-        if ws > 1:
+        if use_dist and _dist() is not None:   # also a one-rank group: distributed=True asks for the collective path
             if local is None:  # this rank got no simulation of the bucket: contribute empty arrays
                 local = _empty_like_bucket(resolved[idxs[0]], with_summary=True)
             elif "summary" not in local:

@@ -9,6 +9,10 @@ from robotic_mpc_amd import SimulationManager, base_params, packing
 import test_gpu_configs as tg
 
 sets = tg.surface_coeff_sets(256)
+# one-time costs (library load, HIP context, allocator warm-up) are not part of either variant
+_w = SimulationManager(base_params(simulation_time=0.05))
+_w.grid_search({"prediction_horizon": [20]}, surface_coeff_sets=sets[:1])
+_w.run_all()
 for label, thr in (("ragged (one launch)", 2048), ("one launch per horizon", 10**9)):
     packing.RAGGED_MIN_BATCH = thr
     m = SimulationManager(base_params())

@@ -270,6 +270,27 @@ def test_two_rank_sharded_engine_run_equals_single_process(tmp_path):
     assert d["ok"] and d["sharded_equals_unsharded"] and d["world_size"] == 2 and d["n_sims"] == 13
 
 
+@pytest.mark.timeout(600)
+def test_rccl_gather_of_device_results_single_rank(tmp_path):
+    """The transport of the N>1 product path that this one-GPU box can run: a one-rank `nccl` (= RCCL) process group;
+    run_all(distributed=True) gathers the engine's DEVICE tensors with dist.gather into one buffer per array and
+    copies it out on the side stream (distributed.gather_to_root); the result equals the plain run bit for bit."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "dist_engine_check.py"),
+                        "--backend", "nccl"], capture_output=True, text=True, timeout=540, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIST_ENGINE_CHECK ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(line[0][len("DIST_ENGINE_CHECK "):])
+    assert d["ok"] and d["sharded_equals_unsharded"] and d["world_size"] == 1 and d["backend"] == "nccl" and d["n_sims"] == 13
+
+
 def test_reference_dump_comparer_end_to_end(orc, ur10_rb, tmp_path):
     """`python -m robotic_mpc_amd.compare`: a dump in the reference-run format (here produced by the
     oracle, standing in for acados) is re-run on the HIP engine and compared column by column."""
