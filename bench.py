@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="time the rollout alone (parameters resident, results stay in HBM)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (rehearsal of the "
                     "multi-rank control flow on a box with fewer GPUs than ranks: tensors are gathered via the host)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the gather path even with "
+                    "one rank (rehearsal of the RCCL code path on a one-GPU box; launch under torch.distributed.run)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +191,8 @@ def main():
 
     from robotic_mpc_amd import distributed as dmod, engine, robots
 
-    if args.gpus > 1 or world > 1:
+    multi = args.gpus > 1 or world > 1 or args.force_dist
+    if multi:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU (torch.distributed.run), WORLD_SIZE={world}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -214,7 +217,7 @@ def main():
     sizes = [args.batch] * world
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -227,7 +230,7 @@ def main():
         eng.rollout(bufs, 0, pb.Nsim)      # step0 = 0 restarts every simulation from its initial state
         local = dict(bufs)
         local["summary"] = eng.summary(bufs)
-        if world > 1:
+        if multi:
             out = dmod.gather_to_root(local, sizes)           # product path of run_all: device tensors -> RCCL -> one D2H
             torch.cuda.current_stream().synchronize()         # a pass ends when this rank's results have left its buffers
             return out
@@ -245,7 +248,7 @@ def main():
         kernel_ms.append(eng.kernel_ms())  # HIP events on the launch stream (the pass has already waited for the kernel,
     barrier()                              # except with --kernel-only, where this wait is the only sync)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -266,7 +269,7 @@ def main():
     traffic, traffic_src = pmc_traffic(args.batch, pb.N, pb.Nsim, args.solver)
     if args.kernel_only:
         region = "rollout kernel only (parameters resident, results left in HBM)"
-    elif world > 1:
+    elif multi:
         region = ("per rank: mpcb_setup (H2D params) -> rollout -> summary kernel -> "
                   f"{'RCCL' if args.backend == 'nccl' else 'gloo (via host)'} gather of all {len(bufs) + 1} result arrays to rank 0 -> D2H on rank 0")
     else:
@@ -298,7 +301,7 @@ def main():
     if rank == 0:
         line["cpu_baseline"] = finish_cpu_baseline(cpu_proc) if cpu_proc is not None else None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
