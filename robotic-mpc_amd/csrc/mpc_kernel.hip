@@ -237,14 +237,66 @@ __global__ __launch_bounds__(WAVE *NWV, WPE) void mpc_rollout_kernel(Problem pb,
 #ifndef MPCB_STREAM_WPE
 #define MPCB_STREAM_WPE 2
 #endif
+// Two launch shapes:
+//   * one workgroup per simulation, all of [step0, step1) (queue == nullptr);
+//   * WORK QUEUE (batch larger than the wavefronts resident at once): the grid is the resident set, every wavefront
+//     pops items (simulation, chunk of `chunk_steps` closed-loop steps) off an atomic counter, chunk-major -- all
+//     simulations advance together, fast wavefronts take more items, and the launch ends within one chunk of the
+//     balanced time instead of with the slowest pair of whole simulations.  Chunk c of a simulation follows chunk c-1,
+//     which may have run on any CU: the finishing wavefront releases (stores drained, agent-scope release, progress
+//     counter), the next one polls the counter and acquires (MI355X_MICROARCH.md, hand-off recipe).  An item's
+//     predecessor was popped earlier, so it is running or done: no wavefront ever waits for work nobody has taken.  A
+//     bounded poll (QUEUE_TIMEOUT_TICKS of the 100 MHz clock) turns a broken hand-off into an error flag, never a hang.
+//   queue[0] item counter, queue[1] error flag, queue[2 + i] chunks of simulation i done in this launch.
+constexpr long long QUEUE_TIMEOUT_TICKS = 30LL * 100000000LL;
 template <class FT>
 __global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
-                                                                           double *ws_base, size_t ws_stride, Outputs out, int step0, int step1)
+                                                                           double *ws_base, size_t ws_stride, Outputs out, int step0, int step1,
+                                                                           int *queue, int chunk_steps)
 {
-    const int inst = blockIdx.x;
-    if (inst >= pb.batch) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-    se::rollout<FT>(pb, params, &rb, ws_base, ws_stride, out, inst, step0, step1);
+    const bool queued = queue != nullptr;
+    const int n_chunks = queued ? (step1 - step0 + chunk_steps - 1) / chunk_steps : 1;
+    const int n_items = n_chunks * pb.batch;
+    for (;;) {
+        int inst = blockIdx.x, s0 = step0, s1 = step1, c = 0;
+        if (queued) {
+            int q = 0;
+            if (threadIdx.x == 0) q = __hip_atomic_fetch_add(&queue[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= n_items) break;
+            c = q / pb.batch;
+            inst = q - c * pb.batch;
+            s0 = step0 + c * chunk_steps;
+            s1 = s0 + chunk_steps < step1 ? s0 + chunk_steps : step1;
+            if (c > 0) {
+                int ok = 1;
+                if (threadIdx.x == 0) {
+                    const long long t_end = (long long)wall_clock64() + QUEUE_TIMEOUT_TICKS;
+                    while (__hip_atomic_load(&queue[2 + inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) {
+                        if ((long long)wall_clock64() > t_end || __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(&queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                }
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                if (!ok) break;                                           // error flag set: every wavefront drains out
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this CU's L1 may hold lines of an earlier chunk
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        } else if (inst >= pb.batch) {
+            break;
+        }
+        se::rollout<FT>(pb, params, &rb, ws_base, ws_stride, out, inst, s0, s1);
+        if (!queued) break;
+        __builtin_amdgcn_s_waitcnt(0);                                    // every store of this chunk has been acknowledged
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) __hip_atomic_store(&queue[2 + inst], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #endif
 }
 
@@ -330,6 +382,9 @@ struct mpcb_handle {
     int waves_per_sim = 4;
     int wpe = 1;               // latency engine: kernel variant compiled for this many wavefronts per SIMD
     int engine = 0;            // 0: latency engine (mpc_core.h), 1: throughput engine (mpc_stream.h)
+    int *d_queue = nullptr;    // throughput engine, work-queue launches: counter, error flag, per-simulation progress
+    size_t queue_cap = 0;
+    bool queue_used = false;   // the last launch went through the work queue (mpcb_sync checks its error flag)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -405,6 +460,7 @@ void mpcb_destroy(mpcb_handle *h)
     (void)hipSetDevice(h->device);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -534,14 +590,38 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     Outputs out;
     std::memcpy(&out, o, sizeof out);
     if (h->engine == 1) {
+        // at least as many simulations as resident wavefronts: work queue over (simulation, chunk of steps) items.
+        // Measured at N=100, 600 steps (profiles/r02_work_queue.txt): batch 4096 890 -> 968 k steps/s, 2560 668 -> 939 k,
+        // 2048 876 -> 909 k; chunks of 8..20 steps are equivalent, 1 step costs 2.5 %, 50 steps 1.4 %.  SQP_RTI only: full
+        // SQP steps are heavy-tailed, the launch then ends with a few simulations' sequential chains and the hand-off
+        // waits only add to them (batch 4096: 35.5 k steps/s plain, 28.6 - 34.2 k queued).
+        const int slots = h->num_cus * 4 * MPCB_STREAM_WPE;
+        int chunk = 10;
+        if (const char *e = getenv("MPCB_STREAM_CHUNK")) chunk = atoi(e);
+        int nslots = slots;
+        if (const char *e = getenv("MPCB_STREAM_SLOTS")) { if (atoi(e) > 0) nslots = atoi(e); }   // (tests: force hand-offs on small batches)
+        const bool queued = chunk > 0 && h->pb.batch >= nslots && h->pb.solver_type == 1;
+        int *queue = nullptr;
+        if (queued) {
+            const size_t need = (size_t)(2 + h->pb.batch) * sizeof(int);
+            if (need > h->queue_cap) {
+                if (h->d_queue) (void)hipFree(h->d_queue);
+                h->d_queue = nullptr; h->queue_cap = 0;
+                if (hipMalloc((void **)&h->d_queue, need) != hipSuccess) return fail(h, MPCB_ENOMEM, "work queue allocation failed");
+                h->queue_cap = need;
+            }
+            HIPCHK(h, hipMemsetAsync(h->d_queue, 0, need, s));
+            queue = h->d_queue;
+        }
+        h->queue_used = queued;
         HIPCHK(h, hipEventRecord(h->ev0, s));
-        const dim3 sgrid((unsigned)h->pb.batch);
+        const dim3 sgrid((unsigned)(queued ? nslots : h->pb.batch));
         if (h->pb.precision == MPCB_PRECISION_FP32_RICCATI)
             hipLaunchKernelGGL(mpc_stream_kernel<float>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
-                               step0, step1);
+                               step0, step1, queue, chunk);
         else
             hipLaunchKernelGGL(mpc_stream_kernel<double>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
-                               step0, step1);
+                               step0, step1, queue, chunk);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev1, s));
         h->last_stream = s;
@@ -589,6 +669,11 @@ int mpcb_sync(mpcb_handle *h)
     if (!h) return MPCB_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    if (h->engine == 1 && h->queue_used && h->d_queue) {
+        int flag = 0;
+        HIPCHK(h, hipMemcpy(&flag, h->d_queue + 1, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) return fail(h, MPCB_EHIP, "work-queue hand-off timed out (results of this launch are incomplete)");
+    }
     return MPCB_OK;
 }
 

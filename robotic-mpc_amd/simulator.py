@@ -306,6 +306,7 @@ class _EngineRunner:
     def collect(self, ticket):
         eng, stream, bufs, summary = ticket
         stream.synchronize()
+        eng.sync()                      # (also reports a failed work-queue hand-off of the throughput engine)
         out = dict(bufs)
         out["summary"] = summary
         out["_kernel_ms"] = eng.kernel_ms()

@@ -267,3 +267,42 @@ def test_stream_engine_ur5_and_custom_tool_offset(stream_engine, orc):
     ref = orc.run(orc.make_robot(ch, cfgs[0]["t_ee"]), orc.make_params(cfgs[0]))
     _check(out, 0, ref)
     _check(out, 1, ref)
+
+
+def test_work_queue_launch_equals_one_workgroup_per_simulation(monkeypatch, ur10):
+    """Batches larger than the resident wavefronts run as a work queue over (simulation, chunk of steps) items with a
+    release/acquire hand-off between the chunks of a simulation (mpc_kernel.hip).  Forced here on small batches (3
+    wavefronts, chunks of 7 steps: every chunk of every simulation changes hands) and at the real size; both must
+    reproduce the plain launch bit for bit (SQP_RTI only: full SQP keeps one workgroup per simulation)."""
+    from robotic_mpc_amd import engine
+
+    monkeypatch.setenv("MPCB_ENGINE", "stream")
+    cases = [("rti", _jitter(8, seed=3, prediction_horizon=12, simulation_time=0.4)),
+             ("active bounds", _jitter(5, seed=4, prediction_horizon=9, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8))),
+             ("ragged", [_cfg(prediction_horizon=n, simulation_time=0.3) for n in (5, 14, 9, 14, 3, 7, 11)])]
+    for name, cfgs in cases:
+        runs = []
+        for slots, chunk in (("0", "0"), ("3", "7"), ("2", "1")):
+            monkeypatch.setenv("MPCB_STREAM_SLOTS", slots)
+            monkeypatch.setenv("MPCB_STREAM_CHUNK", chunk)
+            e = engine.MpcBatchEngine(0)
+            runs.append(e.run(cfgs, ur10))
+            assert e.launch_info()["engine"] == 1
+            e.close()
+        for other in runs[1:]:
+            for k in runs[0]:
+                if k not in ("solver_time", "plant_time"):
+                    np.testing.assert_array_equal(runs[0][k], other[k], err_msg=f"{name} {k}")
+    # real size: 2560 simulations on 2048 resident wavefronts, default chunk
+    monkeypatch.delenv("MPCB_STREAM_SLOTS", raising=False)
+    cfgs = _jitter(2560, seed=9, prediction_horizon=10, simulation_time=1.2)
+    outs = []
+    for chunk in ("0", "10"):
+        monkeypatch.setenv("MPCB_STREAM_CHUNK", chunk)
+        e = engine.MpcBatchEngine(0)
+        outs.append(e.run(cfgs, ur10))
+        e.close()
+    for k in outs[0]:
+        if k not in ("solver_time", "plant_time"):
+            np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+    assert (outs[1]["status"] == 0).all()
