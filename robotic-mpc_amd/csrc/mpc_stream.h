@@ -354,22 +354,29 @@ struct IpmNorms {
 // multiplier step stored with stage k+1; pi_{k-1} travels in LDS from the previous iteration.
 //   in  : G1 row | G3 [DW..DT] | G2 [R..GV]            (234 doubles)
 //   out : G1 [QW..QT] | G2 [R,Y] | G2 [GAM|GT|RB] | G3 [RG|RD|RM]   (196 doubles)
+// MODE 2 = MODE 0 fused with nlp_res_pass<false> of the step BEFORE (SQP_RTI): the first pass of a step streams every
+// record the NLP residual pass needs, so the dynamics defect BD (an input of this very pass), the cost and acados'
+// residual norms of the previous step's iterate are formed here -- from the rows as they arrive, i.e. before the
+// warm-start clamp touches lam, t -- and the separate sweep disappears.  nlp_out = [cost, stat, eq, ineq, comp];
+// sm.vec[3] holds the x_hat the previous QP was solved for.  The output bundle then carries G2 [R..BD] (210 doubles).
 template <int MODE>
-SE_PASS IpmNorms residual_pass(double a)
+SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
 {
+    constexpr bool FUSE = MODE == 2;
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
     constexpr int I_D = 96, I_L = 174;                       // input image: G1 row | D | lin
-    constexpr int O_W = 0, O_RY = 78, O_G = 88, O_3 = 130;   // output image
+    constexpr int RYW = FUSE ? O_BD + 12 : 10;               // G2 columns written from 0: [R, Y] or [R, Y, pad, BD]
+    constexpr int O_W = 0, O_RY = 78, O_G = O_RY + RYW, O_3 = O_G + 42;   // output image
     Bundle<2, 117> bin;
-    Bundle<2, 98> bout;
+    Bundle<2, (78 + RYW + 42 + 66) / 2> bout;
     {
         const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G3, w.ld, O_DW, 78), segd(w.G2, w.ld, 0, W2_LIN)};
         bin.setup(si, lane);
-        const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, 10), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)};
+        const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, RYW), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)};
         bout.setup(so, lane);
         bout.seek(0, 1);
     }
@@ -378,7 +385,8 @@ SE_PASS IpmNorms residual_pass(double a)
     // block inside the stage loop also make the compiler drain the fetches in flight: same LDS object as the ring).
     const int lj = lane >= 18 && lane < 30 ? lane - 18 : 0;                 // lanes 18..29: bounded component (update) / row of rb
     const bool lj_lo = bnd_lo(P, lj) > -BOUND_INF, lj_hi = bnd_hi(P, lj) < BOUND_INF;
-    const int ci = lane < NW ? lane : 0, cls = ci / 6, cj = ci - cls * 6;     // lanes 0..17: stationarity row
+    // lanes 0..17: stationarity row of the QP; MODE 2: lanes 30..47 hold the same rows for the NLP residual of the row ahead
+    const int ci = lane < NW ? lane : (FUSE && lane >= 30 && lane < 30 + NW ? lane - 30 : 0), cls = ci / 6, cj = ci - cls * 6;
     const bool c_lo = cls < 2 && bnd_lo(P, ci < NB ? ci : 0) > -BOUND_INF, c_hi = cls < 2 && bnd_hi(P, ci < NB ? ci : 0) < BOUND_INF;
     const double cb_lo = bnd_lo(P, ci < NB ? ci : 0), cb_hi = bnd_hi(P, ci < NB ? ci : 0);
     const double k_dt = P.dt, k_2wu = 2.0 * P.w_u, k_c2 = P.w_qddot * P.cq[cj] * P.cq[cj], k_lm = P.lm;
@@ -386,9 +394,67 @@ SE_PASS IpmNorms residual_pass(double a)
     const double k_wy = P.w_task[lane >= 48 && lane < 48 + NTASK ? lane - 48 : 0];
     const double k_ra = lj < 6 ? P.a12[lj] : P.a22[lj - 6], k_rb = lj < 6 ? P.b1[lj] : P.b2[lj - 6];
     const double xh = lane < NX ? sm.xhat[lane] : 0.0;
+    // MODE 2, lanes 0..11: dynamics row / cost share of the NLP residual (nlp_res_pass), x_hat of the previous QP
+    const int jd = lane < 12 ? lane % 6 : 0;
+    const double d_a = lane < 6 ? P.a12[jd] : P.a22[jd], d_b = lane < 6 ? P.b1[jd] : P.b2[jd], d_cq = P.cq[jd];
+    const double d_wt = P.w_task[lane >= 6 && lane < 6 + NTASK ? lane - 6 : 0], k_wq = P.w_qddot;
+    const double xprev = FUSE && lane < NX ? sm.vec[3][lane] : 0.0;
+    double csum = 0.0, n_s = 0, n_e = 0, n_i = 0, n_c = 0;
+    // NLP stationarity / bound violation / complementarity of stage kk from its landed row (multipliers as the QP left
+    // them) -- nlp_res_pass lanes 16..33, here lanes 30..47; ppi = pi_{kk-1}
+    auto nlp_stat = [&](const double *row, const double *ppi, int kk) {
+        if (lane < 30 || lane >= 30 + NW) return;
+        const double *r1 = row, *r2 = row + I_L, *pk = row + O_QPI;
+        const int j = cj;
+        double v = 0.0;
+        if (cls == 0) {
+            if (kk < N) {
+                const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+                v = k_dt * (k_2wu * uj + k_c2 * (uj - vj));
+                v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+            }
+        } else if (cls == 1) {
+            if (kk > 0) {
+                if (kk < N) {
+                    double s_ = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NTASK; i++) s_ += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
+                    v = k_dt * s_ + pk[j];
+                }
+                v -= ppi[j];
+            }
+        } else {
+            if (kk > 0) {
+                if (kk < N) {
+                    const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
+                    v = k_dt * (r2[O_GV + j] * r2[O_Y + 4] + k_c2 * (vj - uj));
+                    v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                }
+                v -= ppi[6 + j];
+            }
+        }
+        const bool hc = cls == 0 ? kk < N : (cls == 1 && kk >= 1 && kk < N);
+        if (hc) {
+            const double curv = r1[ci < 6 ? O_U + ci : O_X + ci - 6];
+            const double *lam = row + O_QLAM, *tt = row + O_QT;
+            if (c_lo) {
+                v -= lam[ci];
+                n_i = fmax(n_i, fabs((cb_lo - curv) + tt[ci]));
+                n_c = fmax(n_c, fabs(lam[ci] * tt[ci]));
+            }
+            if (c_hi) {
+                v += lam[12 + ci];
+                n_i = fmax(n_i, fabs((curv - cb_hi) + tt[12 + ci]));
+                n_c = fmax(n_c, fabs(lam[12 + ci] * tt[12 + ci]));
+            }
+        }
+        if (ci >= 6 && kk == 0) v = 0.0;
+        n_s = fmax(n_s, fabs(v));
+    };
     // update of one landed row: dw += a ddw ; (lam, t) += a (dlam, dt) -- or the warm-start clamp in mode 0
+    constexpr bool STEP = MODE == 1;
     auto upd_row = [&](double *row, int kr) {
-        if (MODE == 1) {
+        if (STEP) {
             if (lane < NW) row[O_QW + lane] += a * row[I_D + lane];
         } else {
             if (kr == 0 && lane < NX) row[O_QW + 6 + lane] = xh - row[O_X + lane];
@@ -399,7 +465,7 @@ SE_PASS IpmNorms residual_pass(double a)
             const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
             const bool blo = hc && lj_lo, bhi = hc && lj_hi;
             double *lam = row + O_QLAM, *t = row + O_QT;
-            if (MODE == 0) {
+            if (!STEP) {
                 if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
                 else { lam[j] = 0.0; t[j] = 1.0; }
                 if (bhi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); }
@@ -421,12 +487,41 @@ SE_PASS IpmNorms residual_pass(double a)
 #ifdef MPCB_NOCOMPUTE
         (void)cur; (void)nxt; store_out(bout, o, lane); return;
 #endif
+        if (FUSE) {
+            // NLP residual of the previous step's iterate, from the rows as they landed (program order: these LDS reads
+            // are issued before the warm-start writes below)
+            if (k == 0) nlp_stat(cur, cur, 0);
+            if (k + 1 <= N) nlp_stat(nxt, cur + O_QPI, k + 1);
+            if (lane < 12) {
+                // dynamics defect (prediction_model.py:317-320) and this stage's share of the cost
+                double v = 0.0;
+                if (k < N) {
+                    const int j = jd;
+                    const double xq = cur[O_X + j], xv = cur[O_X + 6 + j], uj = cur[O_U + j];
+                    v = lane < 6 ? (xq + d_a * xv + d_b * uj) - nxt[O_X + j] : (d_a * xv + d_b * uj) - nxt[O_X + 6 + j];
+                    n_e = fmax(n_e, fabs(v));
+                    if (lane < 6) {
+                        const double qdd = d_cq * (uj - xv);
+                        csum += 0.5 * k_dt * (k_2wu * uj * uj + k_wq * qdd * qdd);
+                    } else if (lane < 6 + NTASK) {
+                        const double r = cur[I_L + O_R + (lane - 6)];
+                        csum += 0.5 * k_dt * d_wt * r * r;
+                    }
+                }
+                if (k == 0) n_i = fmax(n_i, fabs(xprev - cur[O_X + lane]));   // lbx_0 = ubx_0 = x_hat of that QP
+                cur[I_L + O_BD + lane] = v;          // the QP's dynamics residual rb of this stage reads it below
+                o[O_RY + O_BD + lane] = v;
+            } else if (lane < 14) {
+                o[O_RY + 10 + (lane - 12)] = 0.0;    // padding scalars of the record
+            }
+            fence();
+        }
         if (k == 0) { upd_row(cur, 0); fence(); }
         // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
         //      Y (lanes 48..52): y_i = w_i (r_i + G_i . delta_k) -- dw_k was updated when row k was the lookahead row
         if (k + 1 <= N) {
             upd_row(nxt, k + 1);
-            if (MODE == 1 && lane >= 32 && lane < 44) cur[O_QPI + lane - 32] += a * nxt[I_D + 18 + lane - 32];
+            if (STEP && lane >= 32 && lane < 44) cur[O_QPI + lane - 32] += a * nxt[I_D + 18 + lane - 32];
         }
         if (lane >= 48 && lane < 48 + NTASK && k < N) {
             const int i = lane - 48;
@@ -535,6 +630,10 @@ SE_PASS IpmNorms residual_pass(double a)
     });
     IpmNorms r;
     r.ng = wmax(a_g); r.nb = wmax(a_b); r.nd = wmax(a_d); r.nm = wmax(a_m); r.smu = wsum(a_mu); r.nc = wsum(ncl);
+    if (FUSE) {
+        nlp_out[0] = wsum(csum);
+        nlp_out[1] = wmax(n_s); nlp_out[2] = wmax(n_e); nlp_out[3] = wmax(n_i); nlp_out[4] = wmax(n_c);
+    }
     return r;
 }
 
@@ -1002,11 +1101,12 @@ SE_PASS void corrector_pass(double sigma_mu)
 #define SPROF_ADD(i, v)
 #endif
 template <class FT>
-SE_DEV int ipm_solve(int qp_iter_max, int *iters_out)
+SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr)
 {
     SSmem &sm = g_ssm;
     const double tol = sm.P.qp_tol;
-    IpmNorms r = residual_pass<0>(0.0);
+    // nlp_prev: the NLP residual / cost of the previous step's iterate is still to be evaluated -- by this QP's first pass
+    IpmNorms r = nlp_prev ? residual_pass<2>(0.0, nlp_prev) : residual_pass<0>(0.0);
     const double nc = unid(r.nc);
     double mu = nc > 0 ? unid(r.smu) / nc : 0.0;
     int it = 0, status = 1;
@@ -1402,6 +1502,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     const SWs w = sm.w;
     const size_t sbase = (size_t)inst * Nsim;
     bool lin_valid = false;
+    bool res_pending = false;          // SQP_RTI: cost / residual norms of the previous step are formed by this step's first pass
     double lin_cost = 0.0;
     int log_lo = step0 == 0 ? 0 : step0 + 1;
     if (step0 == 0) {
@@ -1433,7 +1534,15 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         if (pb.solver_type == 1) {
             // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
             if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass<false>(nullptr)); }
-            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter);
+            double nlp_prev[5];
+            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, res_pending ? nlp_prev : nullptr);
+            if (res_pending) {
+                // cost and residual norms of step i-1, evaluated by this step's first pass
+                if (lane == 8) out.cost[sbase + i - 1] = nlp_prev[0];
+                if (lane >= 12 && lane < 16) out.residuals[(sbase + i - 1) * 4 + (lane - 12)] =
+                    lane == 12 ? nlp_prev[1] : (lane == 13 ? nlp_prev[2] : (lane == 14 ? nlp_prev[3] : nlp_prev[4]));
+                res_pending = false;
+            }
 #ifdef MPCB_SPROF
             if (lane == 0) { w.state[32 + 5] += wclock() - t0; }
 #endif
@@ -1446,7 +1555,13 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
             fence();
             SPROF_ADD(8, tl);
             SPROF_T0(tn);
-            cost = unid(nlp_res_pass<false>(res4));
+            if (i + 1 < step1) {
+                // the next step's first pass streams the same records: it evaluates the defect, cost and residuals there
+                res_pending = true;
+                if (lane < NX) sm.vec[3][lane] = sm.xhat[lane];        // the x_hat this QP was solved for
+            } else {
+                cost = unid(nlp_res_pass<false>(res4));                // last step of this launch / work item
+            }
             SPROF_ADD(9, tn);
             lin_valid = true;
         } else {
@@ -1528,10 +1643,10 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
             out.status[sbase + i] = status;
             out.sqp_iter[sbase + i] = sqp_iter;
             out.qp_iter[sbase + i] = qp_iter;
-            out.cost[sbase + i] = cost;
+            if (!res_pending) out.cost[sbase + i] = cost;
             out.solver_time[sbase + i] = t1 - t0;
         }
-        if (lane >= 12 && lane < 16) out.residuals[(sbase + i) * 4 + (lane - 12)] =
+        if (!res_pending && lane >= 12 && lane < 16) out.residuals[(sbase + i) * 4 + (lane - 12)] =
             lane == 12 ? res4[0] : (lane == 13 ? res4[1] : (lane == 14 ? res4[2] : res4[3]));
         fence();
         if (lane < NX) sm.xhat[lane] = sm.logv[24 + lane];
