@@ -149,6 +149,10 @@ SE_DEV double unid(double v)
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 SE_DEV double wclock() { return (double)wall_clock64() * 1e-8; }
+// Keeps a value that was loaded ahead of its (exec-masked) use where it is: without it the compiler sinks the load into
+// the role's block, and every block then waits out its own LDS round trip (one s_waitcnt lgkmcnt(0) per block).
+SE_DEV void pin(double &v) { asm volatile("" : "+v"(v)); }
+SE_DEV void pin(D2 &v) { asm volatile("" : "+v"(v)); }
 
 // --------------------------------------------------------------------------------------------- record bundles
 // A BUNDLE is what one stage of a pass reads (or writes): a few segments (byte ranges, multiples of 16 B) of the
@@ -452,6 +456,17 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
         n_s = fmax(n_s, fabs(v));
     };
     // update of one landed row: dw += a ddw ; (lam, t) += a (dlam, dt) -- or the warm-start clamp in mode 0
+    // phase R operand slots: every lane fetches its role's operands up front (idle lanes: offset 0)
+    //   lanes 0..17 stationarity row | 18..29 dynamics residual row | 32.. record copies, pi hand-over
+    const int lc = lane >= 32 ? lane - 32 : 0;
+    const int ix_a = lane < NW ? O_U + cj : (lane < 30 ? O_QW + 6 + lj : (lane >= 48 && lane < 60 ? O_QPI + (lane - 48) : 0));
+    const int ix_b = lane < NW ? O_QW + cj : (lane < 30 ? O_QW + (lj < 6 ? 12 + lj : lj - 6) : 0);
+    const int ix_c = lane < NW ? O_X + 6 + cj : (lane < 30 ? O_QW + (lj < 6 ? lj : 0) : 0);
+    const int ix_d = lane < NW ? O_QW + 12 + cj : (lane < 30 ? I_L + O_BD + lj : 0);
+    const int ix_v = ci < 6 ? O_U + ci : O_X + ci - 6;
+    const int ix_h = ci >= 6 ? ci - 6 : 0;
+    const int ix_c2 = lane >= 32 ? (lc < 7 ? O_QW / 2 + 32 + lc : (lc < 12 ? I_L / 2 + lc - 7 : 0)) : 0;   // 16-byte items
+    static_assert(O_QW % 2 == 0 && I_L % 2 == 0, "copy role layout");
     constexpr bool STEP = MODE == 1;
     auto upd_row = [&](double *row, int kr) {
         if (STEP) {
@@ -536,49 +551,58 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             cur[I_L + O_Y + i] = k_wy * v;
         }
         fence();
-        // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29)
+        // ---- R: residuals, Gamma, gt (lanes 0..17), dynamics residual (lanes 18..29), copies (lanes 32..)
         {
-            const double *r1 = cur, *r2 = cur + I_L;
-            const double *pk = cur + O_QPI, *pm = sm.vec[k & 1];
+            const double *pm = sm.vec[k & 1];
+            // operands first (see ix_*), one LDS round trip for the whole phase
+            double q_a = cur[ix_a], q_b = cur[ix_b], q_c = cur[ix_c], q_d = cur[ix_d];
+            double q_e = cur[O_QPI + cj], q_f = cur[O_QPI + 6 + cj], q_g = cur[O_QW + ci], q_v = cur[ix_v];
+            double l_lo = cur[O_QLAM + ci], t_lo = cur[O_QT + ci], l_hi = cur[O_QLAM + 12 + ci], t_hi = cur[O_QT + 12 + ci];
+            double g0 = cur[I_L + O_GQ + cj], g1 = cur[I_L + O_GQ + 6 + cj], g2 = cur[I_L + O_GQ + 12 + cj], g3 = cur[I_L + O_GQ + 18 + cj],
+                   g4 = cur[I_L + O_GQ + 24 + cj], gv = cur[I_L + O_GV + cj];
+            double y0 = cur[I_L + O_Y], y1 = cur[I_L + O_Y + 1], y2 = cur[I_L + O_Y + 2], y3 = cur[I_L + O_Y + 3], y4 = cur[I_L + O_Y + 4];
+            double q_h = pm[ix_h], q_n = nxt[O_QW + 6 + lj];
+            D2 c1 = ((MPC_LOCAL D2 *)(cur + O_QW))[lc], c2 = ((MPC_LOCAL D2 *)cur)[ix_c2];
+            pin(q_a); pin(q_b); pin(q_c); pin(q_d); pin(q_e); pin(q_f); pin(q_g); pin(q_v);
+            pin(l_lo); pin(t_lo); pin(l_hi); pin(t_hi);
+            pin(g0); pin(g1); pin(g2); pin(g3); pin(g4); pin(gv); pin(y0); pin(y1); pin(y2); pin(y3); pin(y4);
+            pin(q_h); pin(q_n); pin(c1); pin(c2);
             if (lane < NW) {
-                const int j = cj;
                 // stationarity of the QP at w + dw (mpc_core.h stat_cls with `with_delta`), same operation order
                 double rg = 0.0;
                 if (cls == 0) {
                     if (k < N) {
-                        const double uj = r1[O_U + j] + r1[O_QW + j], vj = r1[O_X + 6 + j] + r1[O_QW + 12 + j];
+                        const double uj = q_a + q_b, vj = q_c + q_d;
                         rg = k_dt * (k_2wu * uj + k_c2 * (uj - vj));
-                        rg += k_p1 * pk[j] + k_p2 * pk[6 + j];
-                        rg += k_dt * k_lm * r1[O_QW + j];
+                        rg += k_p1 * q_e + k_p2 * q_f;
+                        rg += k_dt * k_lm * q_b;
                     }
                 } else if (cls == 1) {
                     if (k > 0) {
                         if (k < N) {
                             double s = 0.0;
-#pragma unroll
-                            for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
-                            rg = k_dt * s + pk[j];
+                            s += g0 * y0; s += g1 * y1; s += g2 * y2; s += g3 * y3; s += g4 * y4;
+                            rg = k_dt * s + q_e;
                         }
-                        rg += (k < N ? k_dt : 1.0) * k_lm * r1[O_QW + 6 + j];
-                        rg -= pm[j];
+                        rg += (k < N ? k_dt : 1.0) * k_lm * q_g;
+                        rg -= q_h;
                     }
                 } else {
                     if (k > 0) {
                         if (k < N) {
-                            const double uj = r1[O_U + j] + r1[O_QW + j], vj = r1[O_X + 6 + j] + r1[O_QW + 12 + j];
-                            rg = k_dt * (r2[O_GV + j] * r2[O_Y + 4] + k_c2 * (vj - uj));
-                            rg += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                            const double uj = q_a + q_b, vj = q_c + q_d;
+                            rg = k_dt * (gv * y4 + k_c2 * (vj - uj));
+                            rg += k_p1 * q_e + k_p2 * q_f;
                         }
-                        rg += (k < N ? k_dt : 1.0) * k_lm * r1[O_QW + 12 + j];
-                        rg -= pm[6 + j];
+                        rg += (k < N ? k_dt : 1.0) * k_lm * q_d;
+                        rg -= q_h;
                     }
                 }
                 double gt = rg;
                 if (cls < 2) {
                     const bool hc = cls == 0 ? k < N : (k >= 1 && k < N);
                     const bool blo = hc && c_lo, bhi = hc && c_hi;
-                    const double v_ = r1[cls == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
-                    const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
+                    const double v = hc ? q_v : 0.0, dv = q_g;
                     // both sides are evaluated in every lane and masked by selects (an absent bound holds lam = 0, t = 1:
                     // its terms are exact zeros or are deselected), in the operation order of the branchy form
                     const double it_lo = fast_rcp(t_lo), it_hi = fast_rcp(t_hi);
@@ -608,21 +632,19 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
                 const int i = lj;
                 double v = 0.0;
                 if (k < N) {
-                    const double *dw = cur + O_QW, *dn = nxt + O_QW;
-                    if (i < 6) v = dw[6 + i] + k_ra * dw[12 + i] + k_rb * dw[i];
-                    else v = k_ra * dw[6 + i] + k_rb * dw[i - 6];
-                    v += r2[O_BD + i] - dn[6 + i];
+                    if (i < 6) v = q_a + k_ra * q_b + k_rb * q_c;
+                    else v = k_ra * q_a + k_rb * q_b;
+                    v += q_d - q_n;
                     a_b = fmax(a_b, fabs(v));
                 }
                 o[O_G + 30 + i] = v;
             } else if (lane >= 32) {
-                // the updated QW..QT of this stage and r, y go out with the residual records (39 + 5 items, two per
-                // lane where needed); pi_k for the next stage
-                const int l = lane - 32;
-                ((MPC_LOCAL D2 *)(o + O_W))[l] = ((MPC_LOCAL D2 *)(cur + O_QW))[l];
-                if (l < 7) ((MPC_LOCAL D2 *)(o + O_W))[32 + l] = ((MPC_LOCAL D2 *)(cur + O_QW))[32 + l];
-                else if (l < 12) ((MPC_LOCAL D2 *)(o + O_RY))[l - 7] = ((MPC_LOCAL D2 *)(cur + I_L))[l - 7];
-                else if (l >= 16 && l < 28) sm.vec[(k + 1) & 1][l - 16] = cur[O_QPI + l - 16];
+                // the updated QW..QT of this stage and r, y go out with the residual records (39 + 5 items, two per lane
+                // where needed; MODE 2: BD was put there by its lanes); lanes 48..59: pi_k for the next stage
+                ((MPC_LOCAL D2 *)(o + O_W))[lc] = c1;
+                if (lc < 7) ((MPC_LOCAL D2 *)(o + O_W))[32 + lc] = c2;
+                else if (lc < 12) ((MPC_LOCAL D2 *)(o + O_RY))[lc - 7] = c2;
+                if (lane >= 48 && lane < 60) sm.vec[(k + 1) & 1][lane - 48] = q_a;
             }
         }
         fence();
