@@ -534,20 +534,50 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
         if (k == 0) { upd_row(cur, 0); fence(); }
         // ---- U: update the lookahead row; pi_k += a dpi (stored with stage k+1)
         //      Y (lanes 48..52): y_i = w_i (r_i + G_i . delta_k) -- dw_k was updated when row k was the lookahead row
-        if (k + 1 <= N) {
-            upd_row(nxt, k + 1);
-            if (STEP && lane >= 32 && lane < 44) cur[O_QPI + lane - 32] += a * nxt[I_D + 18 + lane - 32];
+        // operands of every role first (see phase R), then the role blocks on registers
+        const int iy = lane >= 48 && lane < 48 + NTASK ? lane - 48 : 0;
+        double yr = cur[I_L + O_R + iy];
+        double gq0 = cur[I_L + O_GQ + iy * 6], gq1 = cur[I_L + O_GQ + iy * 6 + 1], gq2 = cur[I_L + O_GQ + iy * 6 + 2],
+               gq3 = cur[I_L + O_GQ + iy * 6 + 3], gq4 = cur[I_L + O_GQ + iy * 6 + 4], gq5 = cur[I_L + O_GQ + iy * 6 + 5];
+        double wq0 = cur[O_QW + 6], wq1 = cur[O_QW + 7], wq2 = cur[O_QW + 8], wq3 = cur[O_QW + 9], wq4 = cur[O_QW + 10], wq5 = cur[O_QW + 11];
+        double wv0 = cur[O_QW + 12], wv1 = cur[O_QW + 13], wv2 = cur[O_QW + 14], wv3 = cur[O_QW + 15], wv4 = cur[O_QW + 16], wv5 = cur[O_QW + 17];
+        double gv0 = cur[I_L + O_GV], gv1 = cur[I_L + O_GV + 1], gv2 = cur[I_L + O_GV + 2], gv3 = cur[I_L + O_GV + 3],
+               gv4 = cur[I_L + O_GV + 4], gv5 = cur[I_L + O_GV + 5];
+        if (STEP) {
+            const int lw = lane < NW ? lane : 0, lp = lane >= 32 && lane < 44 ? lane - 32 : 0;
+            double u1 = nxt[O_QW + lw], u2 = nxt[lane < NW ? I_D + lane : I_D + 18 + lp], p1 = cur[O_QPI + lp];
+            double l0 = nxt[O_QLAM + lj], t0 = nxt[O_QT + lj], l1 = nxt[O_QLAM + 12 + lj], t1 = nxt[O_QT + 12 + lj];
+            double d0 = nxt[I_D + 30 + lj], e0 = nxt[I_D + 54 + lj], d1 = nxt[I_D + 42 + lj], e1 = nxt[I_D + 66 + lj];
+            pin(u1); pin(u2); pin(p1); pin(l0); pin(t0); pin(l1); pin(t1); pin(d0); pin(e0); pin(d1); pin(e1);
+            pin(yr); pin(gq0); pin(gq1); pin(gq2); pin(gq3); pin(gq4); pin(gq5);
+            pin(wq0); pin(wq1); pin(wq2); pin(wq3); pin(wq4); pin(wq5); pin(wv0); pin(wv1); pin(wv2); pin(wv3); pin(wv4); pin(wv5);
+            pin(gv0); pin(gv1); pin(gv2); pin(gv3); pin(gv4); pin(gv5);
+            if (k + 1 <= N) {
+                // (upd_row on registers)
+                if (lane < NW) {
+                    nxt[O_QW + lane] = u1 + a * u2;
+                } else if (lane < 30) {
+                    const int j = lj, kr = k + 1;
+                    const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
+                    const bool blo = hc && lj_lo, bhi = hc && lj_hi;
+                    double *lam = nxt + O_QLAM, *t = nxt + O_QT;
+                    lam[j] = blo ? fmax(l0 + a * d0, 1e-16) : l0; t[j] = blo ? fmax(t0 + a * e0, 1e-16) : t0;
+                    lam[12 + j] = bhi ? fmax(l1 + a * d1, 1e-16) : l1; t[12 + j] = bhi ? fmax(t1 + a * e1, 1e-16) : t1;
+                } else if (lane >= 32 && lane < 44) {
+                    cur[O_QPI + lane - 32] = p1 + a * u2;
+                }
+            }
+        } else {
+            pin(yr); pin(gq0); pin(gq1); pin(gq2); pin(gq3); pin(gq4); pin(gq5);
+            pin(wq0); pin(wq1); pin(wq2); pin(wq3); pin(wq4); pin(wq5); pin(wv0); pin(wv1); pin(wv2); pin(wv3); pin(wv4); pin(wv5);
+            pin(gv0); pin(gv1); pin(gv2); pin(gv3); pin(gv4); pin(gv5);
+            if (k + 1 <= N) upd_row(nxt, k + 1);
         }
         if (lane >= 48 && lane < 48 + NTASK && k < N) {
             const int i = lane - 48;
-            const double *r2 = cur + I_L, *dw = cur + O_QW;
-            double v = r2[O_R + i];
-#pragma unroll
-            for (int j = 0; j < 6; j++) v += r2[O_GQ + i * 6 + j] * dw[6 + j];
-            if (i == 4) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
-            }
+            double v = yr;
+            v += gq0 * wq0; v += gq1 * wq1; v += gq2 * wq2; v += gq3 * wq3; v += gq4 * wq4; v += gq5 * wq5;
+            if (i == 4) { v += gv0 * wv0; v += gv1 * wv1; v += gv2 * wv2; v += gv3 * wv3; v += gv4 * wv4; v += gv5 * wv5; }
             cur[I_L + O_Y + i] = k_wy * v;
         }
         fence();
