@@ -948,9 +948,14 @@ SE_PASS StepInfo forward_pass()
     const int j6 = j12 % 6;
     const FT a12 = (FT)P.a12[j6], a22 = (FT)P.a22[j6], b1 = (FT)P.b1[j6], b2 = (FT)P.b2[j6];
     double al = 1.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    int tro[12];                                                   // dpi role: packed offsets of its row of P
+    // the 12 factor entries a lane multiplies with dx_k, by role: row i of K (state recursion, lanes 0..11, and input
+    // step, lanes 16..21) or the packed offsets of a row of P (dpi, lanes 32..43); `ex`: the role's additive entry
+    int tix[12];
+    const int krow = lane < 12 ? (lane < 6 ? lane : lane - 6) : (lane >= 16 && lane < 22 ? lane - 16 : 0);
 #pragma unroll
-    for (int i = 0; i < NX; i++) tro[i] = tri_sym(lane >= 32 && lane < 44 ? lane - 32 : 0, i);
+    for (int i = 0; i < NX; i++) tix[i] = lane >= 32 && lane < 44 ? SPM + tri_sym(lane - 32, i) : SK + krow * 12 + i;
+    const int ex = lane < 12 ? SEo + lane : (lane >= 16 && lane < 22 ? SVH + (lane - 16) : (lane >= 32 && lane < 44 ? SPV + (lane - 32) : 0));
+    const int lo12 = lane < 12 ? lane : 0, lov = lane < 6 ? lane + 6 : (lane < 12 ? lane : 0);
     const int jl = lane >= 48 && lane < 60 ? lane - 48 : 0;        // lagging role: bounded component
     const bool jl_lo = bnd_lo(P, jl) > -BOUND_INF, jl_hi = bnd_hi(P, jl) < BOUND_INF;
     if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
@@ -962,22 +967,35 @@ SE_PASS StepInfo forward_pass()
         (void)row; (void)rowp; (void)fac; (void)o; if (k >= 1) store_out(bout, AFFINE ? op + 30 : op, lane); return;
 #endif
         const double *dxk = sm.vec[k & 1];
+        // operands of all four roles first (one LDS round trip per stage), then the role blocks on registers
+        FT m[12];
+        double x[12];
+#pragma unroll
+        for (int j = 0; j < NX; j++) { m[j] = fac[tix[j]]; x[j] = dxk[j]; }
+        FT e1 = fac[ex];
+        double own_d = dxk[lo12], ov_d = dxk[lov];
+        const double *lt = rowp + I_LT, *r = rowp + I_R;
+        double dvl = op[jl], ll = lt[jl], tl = lt[24 + jl], lu = lt[12 + jl], tu = lt[36 + jl];
+        double rdl = r[jl], rdu = r[12 + jl], rml = r[24 + jl], rmu = r[36 + jl];
+#pragma unroll
+        for (int j = 0; j < NX; j++) { asm volatile("" : "+v"(m[j])); pin(x[j]); }
+        asm volatile("" : "+v"(e1));
+        pin(own_d); pin(ov_d); pin(dvl); pin(ll); pin(tl); pin(lu); pin(tu); pin(rdl); pin(rdu); pin(rml); pin(rmu);
         if (lane < 12 && k <= N) {
-            const int i = lane < 6 ? lane : lane - 6;
             FT s0 = (FT)0, s1 = (FT)0;
 #pragma unroll
-            for (int j = 0; j < NX; j += 2) { s0 += fac[SK + i * 12 + j] * (FT)dxk[j]; s1 += fac[SK + i * 12 + j + 1] * (FT)dxk[j + 1]; }
-            const FT kd = s0 + s1, own = (FT)dxk[lane], ov = (FT)dxk[lane < 6 ? lane + 6 : lane];
-            const FT v = fac[SEo + lane] + (lane < 6 ? own + a12 * ov - b1 * kd : a22 * own - b2 * kd);
+            for (int j = 0; j < NX; j += 2) { s0 += m[j] * (FT)x[j]; s1 += m[j + 1] * (FT)x[j + 1]; }
+            const FT kd = s0 + s1, own = (FT)own_d, ov = (FT)ov_d;
+            const FT v = e1 + (lane < 6 ? own + a12 * ov - b1 * kd : a22 * own - b2 * kd);
             o[6 + lane] = (double)own;                              // dx_k
             sm.vec[(k + 1) & 1][lane] = (double)v;                  // dx_{k+1}
         } else if (lane >= 16 && lane < 22 && k <= N) {
             const int j = lane - 16;
             double dv = 0.0;
             if (k < N) {
-                FT s0 = fac[SVH + j], s1 = (FT)0;
+                FT s0 = e1, s1 = (FT)0;
 #pragma unroll
-                for (int i = 0; i < NX; i += 2) { s0 += fac[SK + j * 12 + i] * (FT)dxk[i]; s1 += fac[SK + j * 12 + i + 1] * (FT)dxk[i + 1]; }
+                for (int i = 0; i < NX; i += 2) { s0 += m[i] * (FT)x[i]; s1 += m[i + 1] * (FT)x[i + 1]; }
                 dv = -(double)(s0 + s1);
             }
             o[j] = dv;                                              // du_k (stage N has no input: 0)
@@ -985,20 +1003,17 @@ SE_PASS StepInfo forward_pass()
             const int j = lane - 32;
             double v = 0.0;
             if (k >= 1) {
-                FT s0 = fac[SPV + j], s1 = (FT)0;
+                FT s0 = e1, s1 = (FT)0;
 #pragma unroll
-                for (int i = 0; i < NX; i += 2) { s0 += fac[SPM + tro[i]] * (FT)dxk[i]; s1 += fac[SPM + tro[i + 1]] * (FT)dxk[i + 1]; }
+                for (int i = 0; i < NX; i += 2) { s0 += m[i] * (FT)x[i]; s1 += m[i + 1] * (FT)x[i + 1]; }
                 v = (double)(s0 + s1);
             }
             o[18 + j] = v;                                          // DPI slot of stage k holds dpi_{k-1}
         } else if (lane >= 48 && lane < 60 && k >= 1) {
             const int j = jl, kp = k - 1;
-            const double *lt = rowp + I_LT, *r = rowp + I_R;
-            const double dv = j < 6 ? op[j] : op[6 + (j - 6)];       // du_{k-1}[j] or dq_{k-1}[j-6]
+            const double dv = dvl;                                  // du_{k-1}[j] or dq_{k-1}[j-6]
             const bool hc = j < 6 ? kp < N : (kp >= 1 && kp < N);
             const bool blo = hc && jl_lo, bhi = hc && jl_hi;
-            const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
-            const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
             double dtl = 0, dll = 0, dtu = 0, dlu = 0;
             if (blo) {
                 dtl = dv + rdl;
