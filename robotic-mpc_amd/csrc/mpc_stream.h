@@ -1083,6 +1083,10 @@ SE_PASS void corrector_pass(double sigma_mu)
     const FT eb = (FT)(je < 6 ? P.b1[je] : P.b2[je - 6]);                                   // e lanes: row of B
     const int jc = lane >= 32 && lane < 44 ? lane - 32 : 0;
     const bool jc_lo = bnd_lo(P, jc) > -BOUND_INF, jc_hi = bnd_hi(P, jc) < BOUND_INF;      // corrector lanes
+    // phase Y: the six factor entries a lane multiplies with h_u: column `lane` of K (p_k lanes) or row i6 of R~^-1 (84 = offset of R~^-1 behind K and w)
+    int fx[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) fx[m] = lane < 12 ? m * 12 + lane : (lane >= 16 && lane < 28 ? 84 + (je < 6 ? je : je - 6) * 6 + m : 0);
     // corrector of one landed row -> sm.gtc[kr & 1] (18 entries) and the RM slot of that row's output image
     auto corr_row = [&](const double *row, int kr, int j) {
         const double *lt = row, *r3 = row + I_3, *dl = row + I_DL, *gtb = row + I_GB;
@@ -1115,43 +1119,78 @@ SE_PASS void corrector_pass(double sigma_mu)
         double *o = sm.out[k & 1];
         MPC_LOCAL FT *ofac = (MPC_LOCAL FT *)(o + 24);             // [VH 6 +2 | E 12 | PV 12]
         const double *pn = sm.vec[(k + 1) & 1];                     // p_{k+1}
-        // ---- X: h_u (lanes 0..5) ; corrector of row k-1 (lanes 32..43)
-        if (lane < 6 && k < N) {
-            const FT t0 = (FT)pn[lane] + wv[lane], t1 = (FT)pn[6 + lane] + wv[6 + lane];
-            sm.vec[2][lane] = (double)((FT)gtc[lane] + hb1 * t0 + hb2 * t1);
-        } else if (lane >= 32 && lane < 44 && k >= 1) {
-            corr_row(rowd, k - 1, lane - 32);
+        // ---- X: h_u (lanes 0..5) ; corrector of row k-1 (lanes 32..43).  Operands of both roles first (one LDS round
+        //      trip per phase), then the role blocks on registers.
+        {
+            const int l5 = lane < 6 ? lane : 0;
+            double pn0 = pn[l5], pn1 = pn[6 + l5], g0 = gtc[l5];
+            FT wv0 = wv[l5], wv1 = wv[6 + l5];
+            const double *lt = rowd, *r3 = rowd + I_3, *dl = rowd + I_DL, *gtd = rowd + I_GB;
+            double ll = lt[jc], tl = lt[24 + jc], lu = lt[12 + jc], tu = lt[36 + jc];
+            double dll = dl[jc], dtl = dl[24 + jc], dlu = dl[12 + jc], dtu = dl[36 + jc];
+            double rdl = r3[18 + jc], rdu = r3[18 + 12 + jc], gt = r3[jc], gb0 = gtd[jc], gb1 = gtd[12 + (jc < 6 ? jc : 0)];
+            pin(pn0); pin(pn1); pin(g0); asm volatile("" : "+v"(wv0)); asm volatile("" : "+v"(wv1));
+            pin(ll); pin(tl); pin(lu); pin(tu); pin(dll); pin(dtl); pin(dlu); pin(dtu); pin(rdl); pin(rdu); pin(gt); pin(gb0); pin(gb1);
+            if (lane < 6 && k < N) {
+                const FT t0 = (FT)pn0 + wv0, t1 = (FT)pn1 + wv1;
+                sm.vec[2][lane] = (double)((FT)g0 + hb1 * t0 + hb2 * t1);
+            } else if (lane >= 32 && lane < 44 && k >= 1) {
+                // (corr_row of row k-1 on registers)
+                const int kr = k - 1, j = jc;
+                double *og = sm.gtc[kr & 1], *rmo = sm.out[kr & 1];
+                const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
+                const bool blo = hc && jc_lo, bhi = hc && jc_hi;
+                const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
+                const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
+                gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
+                gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                og[j] = hc ? gt : gb0;
+                if (j < 6) og[12 + j] = gb1;
+                rmo[j] = rml; rmo[12 + j] = rmu;
+            }
         }
         fence();
         // ---- Y: p_k (lanes 0..11), R~^-1 h_u and e (lanes 16..27)
-        if (lane < 12) {
-            FT pj;
-            if (k == N) {
-                pj = (FT)gtc[6 + lane];
-            } else {
-                const FT t = (FT)pn[lane] + wv[lane];
-                const FT oq = lane >= 6 ? (FT)pn[lane - 6] + wv[lane - 6] : (FT)0;
-                FT s0 = (FT)0, s1 = (FT)0;
+        {
+            const int l12 = lane < 12 ? lane : 0, l6 = l12 >= 6 ? l12 - 6 : 0;
+            double gc = gtc[6 + l12], pa = pn[l12], pb = pn[l6], gb = gtb[18 + je];
+            FT wa = wv[l12], wb = wv[l6];
+            FT fm[6];
+            double hm[6];
 #pragma unroll
-                for (int m = 0; m < 6; m += 2) { s0 += kf[m * 12 + lane] * (FT)sm.vec[2][m]; s1 += kf[(m + 1) * 12 + lane] * (FT)sm.vec[2][m + 1]; }
-                pj = (FT)gtc[6 + lane] + (lane < 6 ? t : va12 * oq + va22 * t) - (s0 + s1);
-            }
-            sm.vec[k & 1][lane] = (double)pj;
-            ofac[20 + lane] = pj;
-        } else if (lane >= 16 && lane < 28) {
-            const int j = lane - 16, i6 = j < 6 ? j : j - 6;
-            FT vh = (FT)0, e = (FT)0;
-            if (k < N) {
-                FT v0 = (FT)0, v1 = (FT)0;
+            for (int m = 0; m < 6; m++) { fm[m] = kf[fx[m]]; hm[m] = sm.vec[2][m]; }
+            pin(gc); pin(pa); pin(pb); pin(gb); asm volatile("" : "+v"(wa)); asm volatile("" : "+v"(wb));
 #pragma unroll
-                for (int m = 0; m < 6; m += 2) { v0 += ri[i6 * 6 + m] * (FT)sm.vec[2][m]; v1 += ri[i6 * 6 + m + 1] * (FT)sm.vec[2][m + 1]; }
-                vh = v0 + v1;
-                e = (FT)gtb[18 + j] - eb * vh;
+            for (int m = 0; m < 6; m++) { asm volatile("" : "+v"(fm[m])); pin(hm[m]); }
+            if (lane < 12) {
+                FT pj;
+                if (k == N) {
+                    pj = (FT)gc;
+                } else {
+                    const FT t = (FT)pa + wa;
+                    const FT oq = lane >= 6 ? (FT)pb + wb : (FT)0;
+                    FT s0 = (FT)0, s1 = (FT)0;
+#pragma unroll
+                    for (int m = 0; m < 6; m += 2) { s0 += fm[m] * (FT)hm[m]; s1 += fm[m + 1] * (FT)hm[m + 1]; }
+                    pj = (FT)gc + (lane < 6 ? t : va12 * oq + va22 * t) - (s0 + s1);
+                }
+                sm.vec[k & 1][lane] = (double)pj;
+                ofac[20 + lane] = pj;
+            } else if (lane >= 16 && lane < 28) {
+                const int j = lane - 16;
+                FT vh = (FT)0, e = (FT)0;
+                if (k < N) {
+                    FT v0 = (FT)0, v1 = (FT)0;
+#pragma unroll
+                    for (int m = 0; m < 6; m += 2) { v0 += fm[m] * (FT)hm[m]; v1 += fm[m + 1] * (FT)hm[m + 1]; }
+                    vh = v0 + v1;
+                    e = (FT)gb - eb * vh;
+                }
+                if (j < 6) ofac[j] = vh;
+                ofac[8 + j] = e;
+            } else if (lane >= 28 && lane < 30) {
+                ofac[6 + (lane - 28)] = (FT)0;
             }
-            if (j < 6) ofac[j] = vh;
-            ofac[8 + j] = e;
-        } else if (lane >= 28 && lane < 30) {
-            ofac[6 + (lane - 28)] = (FT)0;
         }
         fence();
         store_out(bout, o, lane);
