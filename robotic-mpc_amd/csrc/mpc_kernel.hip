@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WAVE *NWV, WPE) void mpc_rollout_kernel(Problem pb,
 //   queue[0] item counter, queue[1] error flag, queue[2 + i] chunks of simulation i done in this launch.
 constexpr long long QUEUE_TIMEOUT_TICKS = 30LL * 100000000LL;
 template <class FT>
-__global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Problem pb, Robot rb, const InstParams *__restrict__ params,
+__global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Problem pb, const Robot *__restrict__ rbd, const InstParams *__restrict__ params,
                                                                            double *ws_base, size_t ws_stride, Outputs out, int step0, int step1,
                                                                            int *queue, int chunk_steps)
 {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Probl
         } else if (inst >= pb.batch) {
             break;
         }
-        se::rollout<FT>(pb, params, &rb, ws_base, ws_stride, out, inst, s0, s1);
+        se::rollout<FT>(pb, params, rbd, ws_base, ws_stride, out, inst, s0, s1);
         if (!queued) break;
         __builtin_amdgcn_s_waitcnt(0);                                    // every store of this chunk has been acknowledged
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -373,6 +373,7 @@ struct mpcb_handle {
     bool ready = false;
     int next_step = 0;
     InstParams *d_params = nullptr;
+    Robot *d_rb = nullptr;     // robot record in device memory (behind the parameter records)
     size_t params_cap = 0;
     double *d_ws = nullptr;
     size_t ws_cap = 0;
@@ -528,13 +529,15 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
     std::memcpy(&h->rb, robot_host, sizeof(Robot));
     std::memcpy(&h->pb, p, sizeof(Problem));
     const size_t pbytes = packed.size() * sizeof(InstParams);
-    if (pbytes > h->params_cap) {
+    if (pbytes + sizeof(Robot) > h->params_cap) {   // the robot record rides behind the parameter records (throughput engine reads it from memory)
         if (h->d_params) (void)hipFree(h->d_params);
         h->d_params = nullptr; h->params_cap = 0;
-        if (hipMalloc((void **)&h->d_params, pbytes) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(params)");
-        h->params_cap = pbytes;
+        if (hipMalloc((void **)&h->d_params, pbytes + sizeof(Robot)) != hipSuccess) return fail(h, MPCB_ENOMEM, "hipMalloc(params)");
+        h->params_cap = pbytes + sizeof(Robot);
     }
     HIPCHK(h, hipMemcpy(h->d_params, packed.data(), pbytes, hipMemcpyHostToDevice));
+    h->d_rb = reinterpret_cast<Robot *>(reinterpret_cast<char *>(h->d_params) + pbytes);
+    HIPCHK(h, hipMemcpy(h->d_rb, &h->rb, sizeof(Robot), hipMemcpyHostToDevice));
     h->engine = pick_engine(p, ragged);
     h->ws_stride = ws_doubles_for(p, ragged);
     const size_t wbytes = (size_t)p->batch * h->ws_stride * sizeof(double);
@@ -617,10 +620,10 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
         HIPCHK(h, hipEventRecord(h->ev0, s));
         const dim3 sgrid((unsigned)(queued ? nslots : h->pb.batch));
         if (h->pb.precision == MPCB_PRECISION_FP32_RICCATI)
-            hipLaunchKernelGGL(mpc_stream_kernel<float>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
+            hipLaunchKernelGGL(mpc_stream_kernel<float>, sgrid, dim3(WAVE), 0, s, h->pb, h->d_rb, h->d_params, h->d_ws, h->ws_stride, out,
                                step0, step1, queue, chunk);
         else
-            hipLaunchKernelGGL(mpc_stream_kernel<double>, sgrid, dim3(WAVE), 0, s, h->pb, h->rb, h->d_params, h->d_ws, h->ws_stride, out,
+            hipLaunchKernelGGL(mpc_stream_kernel<double>, sgrid, dim3(WAVE), 0, s, h->pb, h->d_rb, h->d_params, h->d_ws, h->ws_stride, out,
                                step0, step1, queue, chunk);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev1, s));

@@ -78,14 +78,15 @@ constexpr int OUT_MAX = 232;   // doubles of the largest output bundle (factor r
 // one global_load_lds_dwordx4 writes 64 x 16 B contiguously).  Slot = row % slots; rows k-1, k, k+1 of the sweep are
 // valid while stage k is computed, the slots beyond hold rows in flight.
 #ifndef MPCB_RING_DOUBLES
-#define MPCB_RING_DOUBLES 1280
+#define MPCB_RING_DOUBLES 1476
 #endif
 constexpr int RING_DOUBLES = MPCB_RING_DOUBLES;
-constexpr int SLOGB = 4;       // log columns collected before they leave (LOGB of the latency engine is 8: LDS is scarcer here)
+constexpr int SLOGB = 2;       // log columns collected before they leave (LOGB of the latency engine is 8: here every KB of LDS is
+                               // prefetch depth of the input ring, and the sweeps wait on the memory latency that depth hides)
 
 struct SSmem {
     InstParams P;
-    alignas(16) Robot rb;
+    const Robot *rbp;             // kinematic constants: copied into the (idle) ring by the passes that need them, robot_in_lds()
     SWs w;
     int n_hor, pad0;
     alignas(16) double ring[RING_DOUBLES];
@@ -264,6 +265,18 @@ SE_DEV Ring make_ring()
     rg.slot_doubles = ITEMS * 2;
     rg.slots = RING_DOUBLES / rg.slot_doubles > 12 ? 12 : RING_DOUBLES / rg.slot_doubles;
     return rg;
+}
+// The kinematic constants (105 doubles) are needed by the lane-per-stage passes and the plant log only -- never while a
+// sweep streams through the ring: they borrow its first bytes instead of holding LDS of their own.
+SE_DEV const Robot &robot_in_lds()
+{
+    SSmem &sm = g_ssm;
+    wait_vm<0>();                                            // no fetch of an earlier sweep is still landing in the ring
+    fence();
+    const double *rs = reinterpret_cast<const double *>(sm.rbp);
+    for (int e = threadIdx.x; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) sm.ring[e] = rs[e];
+    fence();
+    return *reinterpret_cast<const Robot *>(sm.ring);
 }
 template <int ITEMS, int NO, bool BACK, int NI, int BI, class F>
 SE_DEV void sweep(Bundle<NI, BI> &bin, int N, int lane, F &&body)
@@ -1272,7 +1285,7 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
 {
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
-    const Robot &rb = sm.rb;
+    const Robot &rb = robot_in_lds();
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
@@ -1438,7 +1451,7 @@ SE_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
 {
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
-    const Robot &rb = sm.rb;
+    const Robot &rb = robot_in_lds();
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
@@ -1556,12 +1569,13 @@ SE_PASS int log_state(const Outputs &out, int inst, int T1, int col, int log_lo)
 {
     SSmem &sm = g_ssm;
     const int lane = threadIdx.x;
+    const Robot &rb = robot_in_lds();
     if (lane == 0) {
         double z[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) z[i] = sm.xhat[i];
-        plant_log(sm.rb, z, sm.logv);
-        task_errors(sm.P, sm.rb, sm.logv, sm.logv + 15, sm.logv + 36);
+        plant_log(rb, z, sm.logv);
+        task_errors(sm.P, rb, sm.logv, sm.logv + 15, sm.logv + 36);
     }
     fence();
     if (lane < LOG_ROWS) {
@@ -1593,10 +1607,8 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         const double *ps = reinterpret_cast<const double *>(params + inst);
         double *pd = reinterpret_cast<double *>(&sm.P);
         for (int e = lane; e < (int)(sizeof(InstParams) / sizeof(double)); e += WAVE) pd[e] = ps[e];
-        const double *rs = reinterpret_cast<const double *>(rbp);
-        double *rd = reinterpret_cast<double *>(&sm.rb);
-        for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += WAVE) rd[e] = rs[e];
         if (lane == 0) {
+            sm.rbp = rbp;
             SWs ws = sws_carve<FT>(ws_base + (size_t)inst * ws_stride, N, pb.solver_type == 0);
             ws.state = ws_base + (size_t)inst * ws_stride + (ws_stride - STATE_DOUBLES);   // at the end of the stride whatever this simulation's horizon
             sm.w = ws;
