@@ -56,7 +56,8 @@ extern "C" {
  * the THROUGHPUT engine (one wavefront per simulation, records streamed; SQP_RTI batches of >= MPCB_STREAM_MIN_BATCH
  * simulations, every fp32-Riccati run, every ragged batch; it implements full SQP too, which MPCB_ENGINE=stream selects).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
  * overrides the choice where both apply. */
-#define MPCB_STREAM_MIN_BATCH 2048
+#define MPCB_STREAM_MIN_BATCH 1280   /* measured crossover at N=100 on one MI355X: 1024 simulations 538 k (latency) vs 444 k,
+                                        1280: 510 k vs 546 k steps/s */
 
 typedef struct mpcb_handle mpcb_handle;
 

@@ -44,8 +44,8 @@ def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
 
 
 # SQP_RTI buckets that differ only in the prediction horizon are merged into one RAGGED launch of the throughput engine
-# once together they reach this many simulations (include/mpcbatch.h MPCB_STREAM_MIN_BATCH: two wavefronts per SIMD)
-RAGGED_MIN_BATCH = 2048
+# once together they reach this many simulations (include/mpcbatch.h MPCB_STREAM_MIN_BATCH: from there the throughput engine wins)
+RAGGED_MIN_BATCH = 1280
 SOLVER_RTI = 1
 
 
