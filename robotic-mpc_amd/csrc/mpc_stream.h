@@ -419,50 +419,54 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
     double csum = 0.0, n_s = 0, n_e = 0, n_i = 0, n_c = 0;
     // NLP stationarity / bound violation / complementarity of stage kk from its landed row (multipliers as the QP left
     // them) -- nlp_res_pass lanes 16..33, here lanes 30..47; ppi = pi_{kk-1}
+    const int ix_v = ci < 6 ? O_U + ci : O_X + ci - 6;      // the bounded variable of stationarity row ci
+    const int ix_h = ci >= 6 ? ci - 6 : 0;                    // its entry of pi_{k-1}
     auto nlp_stat = [&](const double *row, const double *ppi, int kk) {
-        if (lane < 30 || lane >= 30 + NW) return;
+        // operands first, by every lane (idle lanes: row offsets of ci = 0), then the rows on registers
         const double *r1 = row, *r2 = row + I_L, *pk = row + O_QPI;
         const int j = cj;
+        double uj = r1[O_U + j], vj = r1[O_X + 6 + j], pkq = pk[j], pkv = pk[6 + j], pp = ppi[ix_h];
+        double h0 = r2[O_GQ + j], h1 = r2[O_GQ + 6 + j], h2 = r2[O_GQ + 12 + j], h3 = r2[O_GQ + 18 + j], h4 = r2[O_GQ + 24 + j], hv = r2[O_GV + j];
+        double z0 = r2[O_Y], z1 = r2[O_Y + 1], z2 = r2[O_Y + 2], z3 = r2[O_Y + 3], z4 = r2[O_Y + 4];
+        double curv = r1[ix_v], la = row[O_QLAM + ci], ta = row[O_QT + ci], lb = row[O_QLAM + 12 + ci], tb = row[O_QT + 12 + ci];
+        pin(uj); pin(vj); pin(pkq); pin(pkv); pin(pp); pin(h0); pin(h1); pin(h2); pin(h3); pin(h4); pin(hv);
+        pin(z0); pin(z1); pin(z2); pin(z3); pin(z4); pin(curv); pin(la); pin(ta); pin(lb); pin(tb);
+        if (lane < 30 || lane >= 30 + NW) return;
         double v = 0.0;
         if (cls == 0) {
             if (kk < N) {
-                const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
                 v = k_dt * (k_2wu * uj + k_c2 * (uj - vj));
-                v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                v += k_p1 * pkq + k_p2 * pkv;
             }
         } else if (cls == 1) {
             if (kk > 0) {
                 if (kk < N) {
                     double s_ = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NTASK; i++) s_ += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
-                    v = k_dt * s_ + pk[j];
+                    s_ += h0 * z0; s_ += h1 * z1; s_ += h2 * z2; s_ += h3 * z3; s_ += h4 * z4;
+                    v = k_dt * s_ + pkq;
                 }
-                v -= ppi[j];
+                v -= pp;
             }
         } else {
             if (kk > 0) {
                 if (kk < N) {
-                    const double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
-                    v = k_dt * (r2[O_GV + j] * r2[O_Y + 4] + k_c2 * (vj - uj));
-                    v += k_p1 * pk[j] + k_p2 * pk[6 + j];
+                    v = k_dt * (hv * z4 + k_c2 * (vj - uj));
+                    v += k_p1 * pkq + k_p2 * pkv;
                 }
-                v -= ppi[6 + j];
+                v -= pp;
             }
         }
         const bool hc = cls == 0 ? kk < N : (cls == 1 && kk >= 1 && kk < N);
         if (hc) {
-            const double curv = r1[ci < 6 ? O_U + ci : O_X + ci - 6];
-            const double *lam = row + O_QLAM, *tt = row + O_QT;
             if (c_lo) {
-                v -= lam[ci];
-                n_i = fmax(n_i, fabs((cb_lo - curv) + tt[ci]));
-                n_c = fmax(n_c, fabs(lam[ci] * tt[ci]));
+                v -= la;
+                n_i = fmax(n_i, fabs((cb_lo - curv) + ta));
+                n_c = fmax(n_c, fabs(la * ta));
             }
             if (c_hi) {
-                v += lam[12 + ci];
-                n_i = fmax(n_i, fabs((curv - cb_hi) + tt[12 + ci]));
-                n_c = fmax(n_c, fabs(lam[12 + ci] * tt[12 + ci]));
+                v += lb;
+                n_i = fmax(n_i, fabs((curv - cb_hi) + tb));
+                n_c = fmax(n_c, fabs(lb * tb));
             }
         }
         if (ci >= 6 && kk == 0) v = 0.0;
@@ -476,8 +480,6 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
     const int ix_b = lane < NW ? O_QW + cj : (lane < 30 ? O_QW + (lj < 6 ? 12 + lj : lj - 6) : 0);
     const int ix_c = lane < NW ? O_X + 6 + cj : (lane < 30 ? O_QW + (lj < 6 ? lj : 0) : 0);
     const int ix_d = lane < NW ? O_QW + 12 + cj : (lane < 30 ? I_L + O_BD + lj : 0);
-    const int ix_v = ci < 6 ? O_U + ci : O_X + ci - 6;
-    const int ix_h = ci >= 6 ? ci - 6 : 0;
     const int ix_c2 = lane >= 32 ? (lc < 7 ? O_QW / 2 + 32 + lc : (lc < 12 ? I_L / 2 + lc - 7 : 0)) : 0;   // 16-byte items
     static_assert(O_QW % 2 == 0 && I_L % 2 == 0, "copy role layout");
     constexpr bool STEP = MODE == 1;
@@ -519,24 +521,26 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             // NLP residual of the previous step's iterate, from the rows as they landed (program order: these LDS reads
             // are issued before the warm-start writes below)
             if (k == 0) nlp_stat(cur, cur, 0);
+            // (the defect lanes' operands go out with the stationarity lanes': one round trip for both)
+            const int l12 = lane < 12 ? lane : 0;
+            double b_xq = cur[O_X + jd], b_xv = cur[O_X + 6 + jd], b_u = cur[O_U + jd], b_xn = nxt[O_X + l12], b_x0 = cur[O_X + l12];
+            double b_r = cur[I_L + O_R + (lane >= 6 && lane < 6 + NTASK ? lane - 6 : 0)];
             if (k + 1 <= N) nlp_stat(nxt, cur + O_QPI, k + 1);
+            pin(b_xq); pin(b_xv); pin(b_u); pin(b_xn); pin(b_x0); pin(b_r);
             if (lane < 12) {
                 // dynamics defect (prediction_model.py:317-320) and this stage's share of the cost
                 double v = 0.0;
                 if (k < N) {
-                    const int j = jd;
-                    const double xq = cur[O_X + j], xv = cur[O_X + 6 + j], uj = cur[O_U + j];
-                    v = lane < 6 ? (xq + d_a * xv + d_b * uj) - nxt[O_X + j] : (d_a * xv + d_b * uj) - nxt[O_X + 6 + j];
+                    v = lane < 6 ? (b_xq + d_a * b_xv + d_b * b_u) - b_xn : (d_a * b_xv + d_b * b_u) - b_xn;
                     n_e = fmax(n_e, fabs(v));
                     if (lane < 6) {
-                        const double qdd = d_cq * (uj - xv);
-                        csum += 0.5 * k_dt * (k_2wu * uj * uj + k_wq * qdd * qdd);
+                        const double qdd = d_cq * (b_u - b_xv);
+                        csum += 0.5 * k_dt * (k_2wu * b_u * b_u + k_wq * qdd * qdd);
                     } else if (lane < 6 + NTASK) {
-                        const double r = cur[I_L + O_R + (lane - 6)];
-                        csum += 0.5 * k_dt * d_wt * r * r;
+                        csum += 0.5 * k_dt * d_wt * b_r * b_r;
                     }
                 }
-                if (k == 0) n_i = fmax(n_i, fabs(xprev - cur[O_X + lane]));   // lbx_0 = ubx_0 = x_hat of that QP
+                if (k == 0) n_i = fmax(n_i, fabs(xprev - b_x0));   // lbx_0 = ubx_0 = x_hat of that QP
                 cur[I_L + O_BD + lane] = v;          // the QP's dynamics residual rb of this stage reads it below
                 o[O_RY + O_BD + lane] = v;
             } else if (lane < 14) {
