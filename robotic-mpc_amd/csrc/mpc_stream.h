@@ -588,7 +588,24 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             pin(yr); pin(gq0); pin(gq1); pin(gq2); pin(gq3); pin(gq4); pin(gq5);
             pin(wq0); pin(wq1); pin(wq2); pin(wq3); pin(wq4); pin(wq5); pin(wv0); pin(wv1); pin(wv2); pin(wv3); pin(wv4); pin(wv5);
             pin(gv0); pin(gv1); pin(gv2); pin(gv3); pin(gv4); pin(gv5);
-            if (k + 1 <= N) upd_row(nxt, k + 1);
+            double l0 = nxt[O_QLAM + lj], t0 = nxt[O_QT + lj], l1 = nxt[O_QLAM + 12 + lj], t1 = nxt[O_QT + 12 + lj];
+            pin(l0); pin(t0); pin(l1); pin(t1);
+            if (k + 1 <= N) {
+                // (upd_row of the lookahead row on registers: warm-start clamp; the row is never row 0)
+                const int kr = k + 1;
+                if (kr == N && lane >= 12 && lane < 18) nxt[O_QW + lane - 12] = 0.0;
+                if (lane >= 18 && lane < 30) {
+                    const int j = lj;
+                    const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
+                    const bool blo = hc && lj_lo, bhi = hc && lj_hi;
+                    double *lam = nxt + O_QLAM, *t = nxt + O_QT;
+                    if (blo) { lam[j] = fmax(l0, 0.1); t[j] = fmax(t0, 0.1); }
+                    else { lam[j] = 0.0; t[j] = 1.0; }
+                    if (bhi) { lam[12 + j] = fmax(l1, 0.1); t[12 + j] = fmax(t1, 0.1); }
+                    else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                    ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
+                }
+            }
         }
         if (lane >= 48 && lane < 48 + NTASK && k < N) {
             const int i = lane - 48;
