@@ -917,25 +917,38 @@ SE_PASS void fact_pass()
         } else if (lane >= 40 && lane < 52) {
             // (register arrays are only ever indexed by constants: a lane-dependent index would put them in scratch memory,
             // and a scratch load in the stage loop drains every fetch in flight)
+            // operands of the whole block first (none of them is computed here): one LDS round trip instead of six
+            const int i6 = jv < 6 ? jv : jv - 6;
+            double g_[6], v1_[12];
+            FT kf_[6], ri_[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) { g_[m] = gt[m]; kf_[m] = (FT)sm.Kf[m * 12 + jv]; ri_[m] = fac[SRI + i6 * 6 + m]; }
+#pragma unroll
+            for (int m = 0; m < NX; m++) v1_[m] = sm.vec[1][m];
+            double t_d = sm.vec[1][jv], oq_d = sm.vec[1][jv >= 6 ? jv - 6 : jv], gj_d = gt[6 + jv], rb_d = rbv[jv];
+#pragma unroll
+            for (int m = 0; m < 6; m++) { pin(g_[m]); asm volatile("" : "+v"(kf_[m])); asm volatile("" : "+v"(ri_[m])); }
+#pragma unroll
+            for (int m = 0; m < NX; m++) pin(v1_[m]);
+            pin(t_d); pin(oq_d); pin(gj_d); pin(rb_d);
             FT hu[6];
 #pragma unroll
-            for (int m = 0; m < 6; m++) hu[m] = (FT)gt[m] + b1r[m] * (FT)sm.vec[1][m] + b2r[m] * (FT)sm.vec[1][6 + m];
-            const FT t = (FT)sm.vec[1][jv];
-            const FT oq = (FT)sm.vec[1][jv >= 6 ? jv - 6 : jv];
-            FT pj = (FT)gt[6 + jv] + (jv < 6 ? t : va12 * oq + va22 * t);
+            for (int m = 0; m < 6; m++) hu[m] = (FT)g_[m] + b1r[m] * (FT)v1_[m] + b2r[m] * (FT)v1_[6 + m];
+            const FT t = (FT)t_d;
+            const FT oq = (FT)oq_d;
+            FT pj = (FT)gj_d + (jv < 6 ? t : va12 * oq + va22 * t);
             FT s0 = (FT)0, s1 = (FT)0;
 #pragma unroll
-            for (int m = 0; m < 6; m += 2) { s0 += (FT)sm.Kf[m * 12 + jv] * hu[m]; s1 += (FT)sm.Kf[(m + 1) * 12 + jv] * hu[m + 1]; }
+            for (int m = 0; m < 6; m += 2) { s0 += kf_[m] * hu[m]; s1 += kf_[m + 1] * hu[m + 1]; }
             pj -= s0 + s1;
             pr = pj;
             fac[SPV + jv] = pj;
-            const int i6 = jv < 6 ? jv : jv - 6;
             FT v0 = (FT)0, v1 = (FT)0;
 #pragma unroll
-            for (int m = 0; m < 6; m += 2) { v0 += fac[SRI + i6 * 6 + m] * hu[m]; v1 += fac[SRI + i6 * 6 + m + 1] * hu[m + 1]; }
+            for (int m = 0; m < 6; m += 2) { v0 += ri_[m] * hu[m]; v1 += ri_[m + 1] * hu[m + 1]; }
             const FT vh = v0 + v1;
             if (jv < 6) fac[SVH + jv] = vh;
-            fac[SEo + jv] = (FT)rbv[jv] - vb * vh;
+            fac[SEo + jv] = (FT)rb_d - vb * vh;
         } else if (lane >= 52 && lane < 56) {
             // padding scalars of the record: defined values
             if (lane < 54) fac[SVH + 6 + (lane - 52)] = (FT)0;
