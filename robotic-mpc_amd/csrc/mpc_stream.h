@@ -874,10 +874,16 @@ SE_PASS void fact_pass()
                     for (int i = 0; i < 6; i++) fac[SRI + i * 6 + (lane - 12)] = x[i];
                 }
             } else if (lane >= 40 && lane < 52) {
-                // t = p_{k+1} + P_{k+1} rb_k
+                // t = p_{k+1} + P_{k+1} rb_k (all 24 operands first: the compiler otherwise fetches them in four batches)
+                FT pm_[12];
+                double rb_[12];
+#pragma unroll
+                for (int j = 0; j < NX; j++) { pm_[j] = facn[SPM + tro[j]]; rb_[j] = rbv[j]; }
+#pragma unroll
+                for (int j = 0; j < NX; j++) { asm volatile("" : "+v"(pm_[j])); pin(rb_[j]); }
                 FT w0 = (FT)0, w1 = (FT)0;
 #pragma unroll
-                for (int j = 0; j < NX; j += 2) { w0 += facn[SPM + tro[j]] * (FT)rbv[j]; w1 += facn[SPM + tro[j + 1]] * (FT)rbv[j + 1]; }
+                for (int j = 0; j < NX; j += 2) { w0 += pm_[j] * (FT)rb_[j]; w1 += pm_[j + 1] * (FT)rb_[j + 1]; }
                 const FT wv = w0 + w1;
                 fac[SWV + jv] = wv;
                 sm.vec[1][jv] = (double)(pr + wv);
