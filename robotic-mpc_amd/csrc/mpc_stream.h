@@ -1034,34 +1034,21 @@ SE_PASS StepInfo forward_pass()
         for (int j = 0; j < NX; j++) { asm volatile("" : "+v"(m[j])); pin(x[j]); }
         asm volatile("" : "+v"(e1));
         pin(own_d); pin(ov_d); pin(dvl); pin(ll); pin(tl); pin(lu); pin(tu); pin(rdl); pin(rdu); pin(rml); pin(rmu);
-        if (lane < 12 && k <= N) {
-            FT s0 = (FT)0, s1 = (FT)0;
+        // the three roles that multiply a factor row with dx_k share ONE dot product (same instruction sequence, per-lane
+        // operands; the input-step and dpi roles start their even-term sum from their additive entry, as before)
+        FT s0 = lane < 12 ? (FT)0 : e1, s1 = (FT)0;
 #pragma unroll
-            for (int j = 0; j < NX; j += 2) { s0 += m[j] * (FT)x[j]; s1 += m[j + 1] * (FT)x[j + 1]; }
-            const FT kd = s0 + s1, own = (FT)own_d, ov = (FT)ov_d;
+        for (int j = 0; j < NX; j += 2) { s0 += m[j] * (FT)x[j]; s1 += m[j + 1] * (FT)x[j + 1]; }
+        const FT kd = s0 + s1;
+        if (lane < 12 && k <= N) {
+            const FT own = (FT)own_d, ov = (FT)ov_d;
             const FT v = e1 + (lane < 6 ? own + a12 * ov - b1 * kd : a22 * own - b2 * kd);
             o[6 + lane] = (double)own;                              // dx_k
             sm.vec[(k + 1) & 1][lane] = (double)v;                  // dx_{k+1}
         } else if (lane >= 16 && lane < 22 && k <= N) {
-            const int j = lane - 16;
-            double dv = 0.0;
-            if (k < N) {
-                FT s0 = e1, s1 = (FT)0;
-#pragma unroll
-                for (int i = 0; i < NX; i += 2) { s0 += m[i] * (FT)x[i]; s1 += m[i + 1] * (FT)x[i + 1]; }
-                dv = -(double)(s0 + s1);
-            }
-            o[j] = dv;                                              // du_k (stage N has no input: 0)
+            o[lane - 16] = k < N ? -(double)kd : 0.0;               // du_k (stage N has no input: 0)
         } else if (!AFFINE && lane >= 32 && lane < 44 && k <= N) {
-            const int j = lane - 32;
-            double v = 0.0;
-            if (k >= 1) {
-                FT s0 = e1, s1 = (FT)0;
-#pragma unroll
-                for (int i = 0; i < NX; i += 2) { s0 += m[i] * (FT)x[i]; s1 += m[i + 1] * (FT)x[i + 1]; }
-                v = (double)(s0 + s1);
-            }
-            o[18 + j] = v;                                          // DPI slot of stage k holds dpi_{k-1}
+            o[18 + (lane - 32)] = k >= 1 ? (double)kd : 0.0;        // DPI slot of stage k holds dpi_{k-1}
         } else if (lane >= 48 && lane < 60 && k >= 1) {
             const int j = jl, kp = k - 1;
             const double dv = dvl;                                  // du_{k-1}[j] or dq_{k-1}[j-6]
