@@ -1202,6 +1202,11 @@ SE_PASS void corrector_pass(double sigma_mu)
             pin(gc); pin(pa); pin(pb); pin(gb); asm volatile("" : "+v"(wa)); asm volatile("" : "+v"(wb));
 #pragma unroll
             for (int m = 0; m < 6; m++) { asm volatile("" : "+v"(fm[m])); pin(hm[m]); }
+            // both roles multiply six factor entries with h_u: one dot product for the two
+            FT d0 = (FT)0, d1 = (FT)0;
+#pragma unroll
+            for (int m = 0; m < 6; m += 2) { d0 += fm[m] * (FT)hm[m]; d1 += fm[m + 1] * (FT)hm[m + 1]; }
+            const FT dd = d0 + d1;
             if (lane < 12) {
                 FT pj;
                 if (k == N) {
@@ -1209,10 +1214,7 @@ SE_PASS void corrector_pass(double sigma_mu)
                 } else {
                     const FT t = (FT)pa + wa;
                     const FT oq = lane >= 6 ? (FT)pb + wb : (FT)0;
-                    FT s0 = (FT)0, s1 = (FT)0;
-#pragma unroll
-                    for (int m = 0; m < 6; m += 2) { s0 += fm[m] * (FT)hm[m]; s1 += fm[m + 1] * (FT)hm[m + 1]; }
-                    pj = (FT)gc + (lane < 6 ? t : va12 * oq + va22 * t) - (s0 + s1);
+                    pj = (FT)gc + (lane < 6 ? t : va12 * oq + va22 * t) - dd;
                 }
                 sm.vec[k & 1][lane] = (double)pj;
                 ofac[20 + lane] = pj;
@@ -1220,10 +1222,7 @@ SE_PASS void corrector_pass(double sigma_mu)
                 const int j = lane - 16;
                 FT vh = (FT)0, e = (FT)0;
                 if (k < N) {
-                    FT v0 = (FT)0, v1 = (FT)0;
-#pragma unroll
-                    for (int m = 0; m < 6; m += 2) { v0 += fm[m] * (FT)hm[m]; v1 += fm[m + 1] * (FT)hm[m + 1]; }
-                    vh = v0 + v1;
+                    vh = dd;
                     e = (FT)gb - eb * vh;
                 }
                 if (j < 6) ofac[j] = vh;
