@@ -279,16 +279,19 @@ def test_work_queue_launch_equals_one_workgroup_per_simulation(monkeypatch, ur10
     from robotic_mpc_amd import engine
 
     monkeypatch.setenv("MPCB_ENGINE", "stream")
-    cases = [("rti", _jitter(8, seed=3, prediction_horizon=12, simulation_time=0.4)),
+    fp32 = _jitter(6, seed=5, prediction_horizon=10, simulation_time=0.3)
+    for c in fp32:
+        c["precision"] = 1
+    cases = [("rti", _jitter(8, seed=3, prediction_horizon=12, simulation_time=0.4)), ("fp32 riccati", fp32),
              ("active bounds", _jitter(5, seed=4, prediction_horizon=9, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8))),
              ("ragged", [_cfg(prediction_horizon=n, simulation_time=0.3) for n in (5, 14, 9, 14, 3, 7, 11)])]
     for name, cfgs in cases:
         runs = []
-        for slots, chunk in (("0", "0"), ("3", "7"), ("2", "1")):
+        for slots, chunk, host_chunk in (("0", "0", 0), ("3", "7", 0), ("2", "1", 0), ("3", "4", 13)):
             monkeypatch.setenv("MPCB_STREAM_SLOTS", slots)
             monkeypatch.setenv("MPCB_STREAM_CHUNK", chunk)
             e = engine.MpcBatchEngine(0)
-            runs.append(e.run(cfgs, ur10))
+            runs.append(e.run(cfgs, ur10, step_chunk=host_chunk))     # (last variant: queued launches of 13 steps each)
             assert e.launch_info()["engine"] == 1
             e.close()
         for other in runs[1:]:
