@@ -54,11 +54,13 @@ extern "C" {
 /* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 2-4
  * wavefronts and most of a CU's LDS per simulation; batches up to a few simulations per CU, and every SQP run) and
  * the THROUGHPUT engine (one wavefront per simulation, records streamed; SQP_RTI batches of >= MPCB_STREAM_MIN_BATCH
- * simulations, every fp32-Riccati run, every ragged batch; it implements full SQP too, which MPCB_ENGINE=stream selects).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
+ * simulations, full-SQP batches of >= MPCB_STREAM_MIN_BATCH_SQP simulations running >= 100 steps, every fp32-Riccati run,
+ * every ragged batch).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
  * overrides the choice where both apply.  An SQP_RTI bucket of at least as many simulations as the GPU holds wavefronts of
  * the throughput engine (8 per CU) is launched as a work queue over (simulation, MPCB_STREAM_CHUNK = 10 closed-loop steps)
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
  * within 30 s is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
+#define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on, for runs of >= 100 closed-loop steps */
 #define MPCB_STREAM_MIN_BATCH 1280   /* measured crossover at N=100 on one MI355X: 1024 simulations 538 k (latency) vs 444 k,
                                         1280: 510 k vs 546 k steps/s */
 

@@ -473,10 +473,14 @@ const char *mpcb_last_error(const mpcb_handle *h) { return h ? h->err.c_str() : 
 static int pick_engine(const mpcb_problem *p, bool ragged = false)
 {
     if (p->precision == MPCB_PRECISION_FP32_RICCATI || ragged) return 1;
-    // full SQP keeps the latency engine by default although the throughput engine implements it: SQP work per step is
-    // heavy-tailed (a few simulations run into nlp_solver_max_iter), so the launch time is set by per-simulation latency
-    // (measured at batch 4096, N = 100, 50 steps: 42 k steps/s on the latency engine, 33 k on the throughput engine)
-    int e = p->solver_type == MPCB_SOLVER_SQP_RTI && p->batch >= MPCB_STREAM_MIN_BATCH ? 1 : 0;
+    // Full SQP work per step is heavy-tailed while the closed loop settles (a few simulations run into
+    // nlp_solver_max_iter): short or small runs end with those simulations' sequential chains, where the latency engine is
+    // faster per simulation; long runs of large batches are throughput work again, and the work-queue launch balances them.
+    // Measured at N = 100 (profiles/r02_sqp_sweep.txt), throughput engine queued / latency engine, steps/s: batch 4096 x 600
+    // steps 299 k / 214 k, x 100 steps 67 k / 59 k, x 50 steps 34 k / 42 k; batch 3072 x 600: 245 k / 195 k; 2048 x 600: 179 k / 194 k.
+    int e = 0;
+    if (p->solver_type == MPCB_SOLVER_SQP_RTI) e = p->batch >= MPCB_STREAM_MIN_BATCH ? 1 : 0;
+    else e = p->batch >= MPCB_STREAM_MIN_BATCH_SQP && p->Nsim >= 100 ? 1 : 0;
     if (const char *env = getenv("MPCB_ENGINE")) {
         if (!strcmp(env, "stream")) e = 1;
         else if (!strcmp(env, "latency")) e = 0;
@@ -595,15 +599,15 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
     if (h->engine == 1) {
         // at least as many simulations as resident wavefronts: work queue over (simulation, chunk of steps) items.
         // Measured at N=100, 600 steps (profiles/r02_work_queue.txt): batch 4096 890 -> 968 k steps/s, 2560 668 -> 939 k,
-        // 2048 876 -> 909 k; chunks of 8..20 steps are equivalent, 1 step costs 2.5 %, 50 steps 1.4 %.  SQP_RTI only: full
-        // SQP steps are heavy-tailed, the launch then ends with a few simulations' sequential chains and the hand-off
-        // waits only add to them (batch 4096: 35.5 k steps/s plain, 28.6 - 34.2 k queued).
+        // 2048 876 -> 909 k; chunks of 8..20 steps are equivalent, 1 step costs 2.5 %, 50 steps 1.4 %.  Full SQP: only for
+        // runs of >= 100 steps (see pick_engine: the settling phase is heavy-tailed, hand-off waits then add to the chains).
         const int slots = h->num_cus * 4 * MPCB_STREAM_WPE;
         int chunk = 10;
-        if (const char *e = getenv("MPCB_STREAM_CHUNK")) chunk = atoi(e);
+        bool chunk_forced = false;                                   // (an explicit MPCB_STREAM_CHUNK also applies to full SQP)
+        if (const char *e = getenv("MPCB_STREAM_CHUNK")) { chunk = atoi(e); chunk_forced = true; }
         int nslots = slots;
         if (const char *e = getenv("MPCB_STREAM_SLOTS")) { if (atoi(e) > 0) nslots = atoi(e); }   // (tests: force hand-offs on small batches)
-        const bool queued = chunk > 0 && h->pb.batch >= nslots && h->pb.solver_type == 1;
+        const bool queued = chunk > 0 && h->pb.batch >= nslots && (h->pb.solver_type == 1 || chunk_forced || h->pb.Nsim >= 100);
         int *queue = nullptr;
         if (queued) {
             const size_t need = (size_t)(2 + h->pb.batch) * sizeof(int);

@@ -275,7 +275,7 @@ def test_work_queue_launch_equals_one_workgroup_per_simulation(monkeypatch, ur10
     """Batches larger than the resident wavefronts run as a work queue over (simulation, chunk of steps) items with a
     release/acquire hand-off between the chunks of a simulation (mpc_kernel.hip).  Forced here on small batches (3
     wavefronts, chunks of 7 steps: every chunk of every simulation changes hands) and at the real size; both must
-    reproduce the plain launch bit for bit (SQP_RTI only: full SQP keeps one workgroup per simulation)."""
+    reproduce the plain launch bit for bit -- SQP_RTI, the fp32-Riccati leg, full SQP, active bounds, a ragged batch."""
     from robotic_mpc_amd import engine
 
     monkeypatch.setenv("MPCB_ENGINE", "stream")
@@ -283,6 +283,7 @@ def test_work_queue_launch_equals_one_workgroup_per_simulation(monkeypatch, ur10
     for c in fp32:
         c["precision"] = 1
     cases = [("rti", _jitter(8, seed=3, prediction_horizon=12, simulation_time=0.4)), ("fp32 riccati", fp32),
+             ("sqp", _jitter(5, seed=4, prediction_horizon=9, simulation_time=0.3, solver_options={"nlp_solver_type": "SQP"})),
              ("active bounds", _jitter(5, seed=4, prediction_horizon=9, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8))),
              ("ragged", [_cfg(prediction_horizon=n, simulation_time=0.3) for n in (5, 14, 9, 14, 3, 7, 11)])]
     for name, cfgs in cases:
