@@ -155,6 +155,36 @@ def test_config3_full_sqp_batch512_matches_oracle(eng, orc, ur10, ur10_rb):
             np.testing.assert_allclose(out[k][i][:, :n + 1], ref[k][:, :n + 1], atol=ATOL, rtol=0, err_msg=f"sim {i} {k}")
 
 
+def test_config3_full_sqp_large_batch_takes_the_work_queue_and_matches_oracle(eng, orc, ur10, ur10_rb):
+    """BASELINE configs[3] at a size where full SQP is throughput work: 2560 simulations (>= MPCB_STREAM_MIN_BATCH_SQP),
+    100 closed-loop steps -> throughput engine, work-queue launch (no env overrides).  Same random coefficients as the
+    batch-512 test; spot checks against the oracle with strict parity up to the first flagged step."""
+    from robotic_mpc_amd import config
+
+    rng_c, rng_r = np.random.default_rng(2), np.random.default_rng(1)
+    base = dict(a=-0.1, b=0.1, c=-0.01, d=0.01, e=0.01, f=0.0)
+    cfgs = []
+    for _ in range(2560):
+        co = {k: float(rng_c.normal(v, 0.01)) for k, v in base.items()}
+        cfgs.append(config.resolve_config(config.base_params(
+            prediction_horizon=100, simulation_time=1.0, surface_coeffs=co, surface_orientation_rpy=rng_r.uniform(-0.3, 0.3, 3),
+            solver_options={"nlp_solver_type": "SQP"})))
+    out = eng.run(cfgs, ur10)
+    assert eng.launch_info()["engine"] == 1 and np.isfinite(out["z"]).all()
+    flagged = int((out["status"] != 0).sum())
+    assert flagged <= 0.02 * out["status"].size, flagged
+    for i in (5, 1300, 2559):
+        ref = _oracle_result(orc, ur10_rb, cfgs[i])
+        bad = np.nonzero((ref["status"] != 0) | (out["status"][i] != 0))[0]
+        n = int(bad[0]) if bad.size else ref["status"].shape[0]
+        assert n >= 50, (i, n)
+        np.testing.assert_array_equal(out["status"][i][:n], ref["status"][:n])
+        np.testing.assert_array_equal(out["sqp_iter"][i][:n], ref["sqp_iter"][:n])
+        np.testing.assert_array_equal(out["qp_iter"][i][:n], ref["qp_iter"][:n])
+        for k in ("z", "u", "errors"):
+            np.testing.assert_allclose(out[k][i][:, :n + 1], ref[k][:, :n + 1], atol=ATOL, rtol=0, err_msg=f"sim {i} {k}")
+
+
 # ------------------------------------------------------------------------------------------- device pieces
 def test_device_linearisation_matches_oracle(eng, orc, ur10, ur10_rb):
     """task_lin on the device (r, dg/dq, dg5/dqdot of trajectory_optimizer.py:104-126 through the analytic
