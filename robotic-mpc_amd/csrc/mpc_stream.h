@@ -12,7 +12,11 @@
 //   * what hides the memory and LDS latency is not a second wavefront of the same simulation but the OTHER
 //     simulations resident on the same SIMD (2 at 256 VGPRs), each with < 20 KB of LDS;
 //   * in every stage the lanes of the wavefront take different roles at once (matrix recursion | vector recursion;
-//     state recursion | input step | multiplier step | step-length terms of the stage before).
+//     state recursion | input step | multiplier step | step-length terms of the stage before).  Roles side by side in
+//     one wavefront execute one after the other (SIMT), so what matters is the length of that chain: every phase of a
+//     stage first fetches the operands of ALL its roles -- per-lane index tables, idle lanes read offset 0, values held
+//     by pin() -- and only then runs the exec-masked role blocks, on registers (one LDS round trip per phase, not one
+//     per block); roles that multiply a factor row with the same vector share one dot product.
 // Record groups G1..G3 in HBM are those of mpc_layout.h; the factor record G4 has its fields padded to multiples
 // of four scalars (S* offsets below) so that every bundle is a whole number of 16-byte items in fp64 AND fp32.
 //
