@@ -160,6 +160,32 @@ def finish_cpu_baseline(proc):
 
 
 # ------------------------------------------------------------------------------------------- main
+def throughput_leg(eng, chain, args):
+    """Secondary figure (NOT `value`): kernel rate of the throughput engine at batch 4096, N=100, 600 closed-loop steps,
+    SQP_RTI (one work-queue launch after one warm-up launch of 60 steps), measured with HIP events like the roofline."""
+    import torch
+
+    B = 4096
+    cfgs = workload_configs(B, args.horizon, args.sim_time, seed=1, solver="SQP_RTI")
+    pb, params, robot = eng.prepare(cfgs, chain)
+    eng.setup_packed(pb, params, robot)
+    bufs = eng.alloc_results(pb)
+    eng.rollout(bufs, 0, min(60, pb.Nsim))
+    eng.sync()
+    eng.rollout(bufs, 0, pb.Nsim)
+    eng.sync()
+    ms = eng.kernel_ms()
+    geo = eng.launch_info()
+    out = {"workload": f"batch={B} UR10 sims on one GPU, N={pb.N}, {pb.Nsim} closed-loop steps, SQP_RTI, flat surface, q_0 jitter rng(1)",
+           "engine": "throughput (one wavefront per simulation, work-queue launch)" if geo["engine"] == 1 else "latency",
+           "kernel_ms": ms, "kernel_steps_per_s": B * pb.Nsim / (ms * 1e-3),
+           "mean_qp_iters_per_step": float(bufs["qp_iter"].double().mean().item()),
+           "solver_failures": int((bufs["status"] != 0).sum().item())}
+    del bufs
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         return cpu_baseline_main(sys.argv[2:])
@@ -175,6 +201,7 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="time the rollout alone (parameters resident, results stay in HBM)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (rehearsal of the "
                     "multi-rank control flow on a box with fewer GPUs than ranks: tensors are gathered via the host)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra (untimed-region) throughput-geometry measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the gather path even with "
                     "one rank (rehearsal of the RCCL code path on a one-GPU box; launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -298,6 +325,9 @@ def main():
                      "fp64_valu_frac": flops_step * steps_per_pass / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "scratch_bytes": info["scratch_bytes"]},
     }
+    if rank == 0 and not multi and not args.no_secondary:
+        # outside the timed region, for the record: the throughput geometry in the same process
+        line["secondary"] = throughput_leg(eng, chain, args)
     if rank == 0:
         line["cpu_baseline"] = finish_cpu_baseline(cpu_proc) if cpu_proc is not None else None
         print(json.dumps(line), flush=True)

@@ -52,3 +52,5 @@ def test_bench_line_on_a_small_workload():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert r["config"]["solver_failures"] == 0
+    sec = r["secondary"]                     # extra record outside the timed region: the throughput geometry
+    assert "4096" in sec["workload"] and sec["engine"].startswith("throughput") and sec["kernel_steps_per_s"] > 0 and sec["solver_failures"] == 0
