@@ -242,6 +242,10 @@ def main():
     eng.setup_packed(pb, params, robot)            # sizes the workspace (allocation is not part of a pass)
     bufs = eng.alloc_results(pb)
     sizes = [args.batch] * world
+    # caller-owned host result buffers (pinned), allocated once like the device ones: allocation is not part of a pass
+    host_bufs = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in bufs.items()}
+    host_bufs["summary"] = torch.empty((args.batch, engine.NSUMMARY), dtype=torch.float64, pin_memory=True)
+    gather_cache = {}
 
     def barrier():
         if multi:
@@ -258,10 +262,10 @@ def main():
         local = dict(bufs)
         local["summary"] = eng.summary(bufs)
         if multi:
-            out = dmod.gather_to_root(local, sizes)           # product path of run_all: device tensors -> RCCL -> one D2H
+            out = dmod.gather_to_root(local, sizes, gather_cache)   # product path of run_all: device tensors -> RCCL -> one D2H
             torch.cuda.current_stream().synchronize()         # a pass ends when this rank's results have left its buffers
             return out
-        return {k: dmod.to_host(v) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
+        return {k: dmod.to_host(v, host_bufs[k]) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
 
     for _ in range(args.warmup):
         one_pass()

@@ -100,7 +100,7 @@ def group_buckets(resolved: Sequence[Dict], parts: int = 1, merge_ragged: bool =
     return out
 
 
-def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[str, np.ndarray]]:
+def gather_to_root(local: Dict[str, object], sizes: List[int], cache: Optional[Dict[str, object]] = None) -> Optional[Dict[str, np.ndarray]]:
     """The one exchange step of a sharded run: gather per-rank arrays [n_r, ...] (n_r = sizes[r]) to rank 0.
 
     ``local`` holds torch tensors (device tensors from the engine) or numpy arrays.  With the ``nccl`` backend
@@ -110,7 +110,9 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
     side stream while the next array is being gathered; one wait at the end.  With ``gloo`` (CPU rehearsal) tensors
     are moved to the host first and the gathered buffer IS the result.  The collective is chosen by the backend alone
     (``dist.gather`` exists for both), never per rank or per exception: ranks that disagree on the collective would
-    deadlock.  Shards are padded to max(sizes) because gather needs equal shapes; the padding rows are cut on rank 0."""
+    deadlock.  Shards are padded to max(sizes) because gather needs equal shapes; the padding rows are cut on rank 0.
+    ``cache`` (a dict the caller keeps between calls of the same shapes) makes rank 0 reuse its gather buffers and pinned
+    host arrays instead of allocating them per call -- the returned arrays are then overwritten by the next call."""
     import torch
     import torch.distributed as dist
 
@@ -130,7 +132,14 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
             pad = torch.zeros((nmax - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
             t = torch.cat([t, pad], dim=0)
         t = t.contiguous()
-        big = torch.empty((ws * nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) if me == 0 else None
+        big = None
+        if me == 0:
+            shape = (ws * nmax,) + tuple(t.shape[1:])
+            big = cache.get("dev:" + name) if cache is not None else None
+            if big is None or tuple(big.shape) != shape or big.dtype != t.dtype:
+                big = torch.empty(shape, dtype=t.dtype, device=dev)
+                if cache is not None:
+                    cache["dev:" + name] = big
         dist.gather(t, list(big.split(nmax, dim=0)) if me == 0 else None, dst=0)
         if me != 0:
             continue
@@ -140,7 +149,11 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
         # (dist.gather has made the current stream wait for the collective: an event recorded now covers it)
         done = torch.cuda.Event()
         done.record()
-        host = torch.empty(big.shape, dtype=big.dtype, pin_memory=True)
+        host = cache.get("host:" + name) if cache is not None else None
+        if host is None or host.shape != big.shape or host.dtype != big.dtype:
+            host = torch.empty(big.shape, dtype=big.dtype, pin_memory=True)
+            if cache is not None:
+                cache["host:" + name] = host
         copy_stream.wait_event(done)
         with torch.cuda.stream(copy_stream):
             host.copy_(big, non_blocking=True)
@@ -157,15 +170,16 @@ def gather_to_root(local: Dict[str, object], sizes: List[int]) -> Optional[Dict[
     return out
 
 
-def to_host(v) -> np.ndarray:
-    """Device tensor -> numpy through a pinned staging buffer (one DMA at PCIe rate); numpy stays numpy."""
+def to_host(v, out=None) -> np.ndarray:
+    """Device tensor -> numpy through a pinned staging buffer (one DMA at PCIe rate); numpy stays numpy.  ``out``: a pinned
+    host tensor of the same shape to copy into (caller-owned result buffer, reused from call to call)."""
     if isinstance(v, np.ndarray):
         return v
     if v.device.type == "cpu":
         return v.numpy()
     import torch
 
-    host = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+    host = out if out is not None else torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
     host.copy_(v, non_blocking=False)
     return host.numpy()
 
