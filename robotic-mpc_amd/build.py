@@ -38,5 +38,15 @@ def build(force: bool = False, profile: bool = False, verbose: bool = False) -> 
     return target
 
 
+def build_variant(name: str, defines) -> str:
+    """Diagnostic builds (scripts/): robotic-mpc_amd/libmpcbatch_<name>.so with extra -D switches, rebuilt when stale."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    target = os.path.join(HERE, f"libmpcbatch_{name}.so")
+    if _stale(target):
+        subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-shared", "-std=c++17", *[f"-D{d}" for d in defines],
+                               "-o", target, os.path.join(CSRC, "mpc_kernel.hip")])
+    return target
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, profile="--profile" in sys.argv, verbose=True))

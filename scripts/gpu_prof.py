@@ -9,7 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 T = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 SOLVER = sys.argv[4] if len(sys.argv) > 4 else "SQP_RTI"
-lib = os.environ.get("MPCB_LIB") or os.path.join(ROOT, "robotic-mpc_amd", "libmpcbatch_prof.so")
+from robotic_mpc_amd import build as _b
+lib = os.environ.get("MPCB_LIB") or _b.build_variant("prof", ["MPCB_PROFILE"])     # (built on demand)
 eng = engine.MpcBatchEngine(0, lib_path=lib)
 print("kernel info", eng.kernel_info())
 ch = robots.builtin_chain("ur10")

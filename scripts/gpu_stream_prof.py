@@ -7,7 +7,8 @@ import numpy as np
 import bench
 from robotic_mpc_amd import engine, robots
 ch = robots.builtin_chain("ur10")
-eng = engine.MpcBatchEngine(0, lib_path=os.path.join(ROOT, "robotic-mpc_amd", os.environ.get("SPROF_LIB", "libmpcbatch_sprof.so")))
+from robotic_mpc_amd import build as _b
+eng = engine.MpcBatchEngine(0, lib_path=_b.build_variant("sprof", ["MPCB_SPROF"]))     # (built on demand)
 for B in [int(v) for v in sys.argv[1:]] or [1024, 2048]:
     cfgs = bench.workload_configs(B, 100, 0.5, seed=1, solver="SQP_RTI")
     pb, bufs = eng.run_device(cfgs, ch)
