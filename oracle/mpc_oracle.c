@@ -4,7 +4,7 @@
  *
  * Everything here is deliberately plain: dense 18x18 stage blocks, textbook
  * Riccati, scalar loops.  It shares no source with the HIP product path
- * (robotic-mpc_amd/csrc), which exploits the block structure instead.
+ * (robotic_mpc_amd/csrc), which exploits the block structure instead.
  *
  * Citations "file:line" are into the reference checkout (/root/reference).
  */

@@ -1,7 +1,7 @@
 """ctypes loader for the CPU oracle (TEST INFRASTRUCTURE -- see mpc_oracle.h).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
-The product path (robotic-mpc_amd/) never does.
+The product path (robotic_mpc_amd/) never does.
 """
 from __future__ import annotations
 

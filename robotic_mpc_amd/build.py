@@ -22,7 +22,7 @@ def _stale(target: str) -> bool:
 
 
 def build(force: bool = False, profile: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> robotic-mpc_amd/libmpcbatch.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> robotic_mpc_amd/libmpcbatch.so (cross-compiles without a GPU)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     target = LIB_PROF if profile else LIB
     if not force and not _stale(target):
@@ -39,7 +39,7 @@ def build(force: bool = False, profile: bool = False, verbose: bool = False) -> 
 
 
 def build_variant(name: str, defines) -> str:
-    """Diagnostic builds (scripts/): robotic-mpc_amd/libmpcbatch_<name>.so with extra -D switches, rebuilt when stale."""
+    """Diagnostic builds (scripts/): robotic_mpc_amd/libmpcbatch_<name>.so with extra -D switches, rebuilt when stale."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     target = os.path.join(HERE, f"libmpcbatch_{name}.so")
     if _stale(target):

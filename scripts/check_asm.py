@@ -10,7 +10,7 @@ usage: python scripts/check_asm.py            (exit code 1 when the pattern is f
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "robotic-mpc_amd", "csrc", "mpc_kernel.hip")
+SRC = os.path.join(ROOT, "robotic_mpc_amd", "csrc", "mpc_kernel.hip")
 
 
 def scan(asm_text):

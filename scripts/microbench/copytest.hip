@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../robotic-mpc_amd/csrc/mpc_core.h"
+#include "../../robotic_mpc_amd/csrc/mpc_core.h"
 using namespace mpcb;
 __shared__ __attribute__((aligned(16))) Smem g_sm;
 extern __shared__ __attribute__((aligned(16))) double g_pool[];

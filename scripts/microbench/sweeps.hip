@@ -4,8 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../robotic-mpc_amd/csrc/mpc_core.h"
-#include "../../robotic-mpc_amd/csrc/mpc_pack.h"
+#include "../../robotic_mpc_amd/csrc/mpc_core.h"
+#include "../../robotic_mpc_amd/csrc/mpc_pack.h"
 using namespace mpcb;
 struct DevExec {
     int lane;

@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmpc_emu.so")
-_CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "robotic-mpc_amd", "csrc")
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "robotic_mpc_amd", "csrc")
 
 
 class Problem(C.Structure):

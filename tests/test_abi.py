@@ -70,8 +70,8 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under robotic-mpc_amd/ may reference it."""
-    pkg = os.path.join(ROOT, "robotic-mpc_amd")
+    """The oracle is test infrastructure: nothing under robotic_mpc_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "robotic_mpc_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".cpp")):

@@ -1,6 +1,6 @@
 """Host emulation of the product's device code (tests/emu) against the oracle.
 
-The HIP engine (robotic-mpc_amd/csrc/mpc_core.h) is a single-source template; here it is
+The HIP engine (robotic_mpc_amd/csrc/mpc_core.h) is a single-source template; here it is
 instantiated with an executor that runs the 64 lanes of each phase sequentially on the CPU.
 This catches lane-mapping / phase-hazard / algebra bugs without a GPU.  It is test
 infrastructure: the product library has no CPU path.
