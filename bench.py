@@ -66,14 +66,14 @@ def pmc_traffic(batch, N, Nsim, solver):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
     (profiles/r02_pmc_summary.json, written by scripts/profile_gpu.sh); None when absent or when it was
     taken on another workload.  The summary names the commit it was profiled at."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if (d.get("batch"), d.get("N"), d.get("Nsim"), d.get("solver")) == (batch, N, Nsim, solver):
-            return float(d["hbm_bytes_per_launch"]), f"profiles/r02_pmc_summary.json (separate --pmc passes, profiled_at_commit {d.get('commit', '?')})"
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if (d.get("batch"), d.get("N"), d.get("Nsim"), d.get("solver")) == (batch, N, Nsim, solver):
+                return float(d["hbm_bytes_per_launch"]), f"profiles/{name} (separate --pmc passes, profiled_at_commit {d.get('commit', '?')})"
+        except (OSError, ValueError, KeyError):
+            pass
     return None, None
 
 
@@ -159,7 +159,57 @@ def finish_cpu_baseline(proc):
     return {"error": "cpu baseline child failed", "stderr": err[-400:]}
 
 
+# ------------------------------------------------------------------------------------------- self launch
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a CHILD process and forward its output and exit code.  This parent has not imported torch or touched HIP (a
+    process that has initialised the GPU must never exec or fork GPU work), and it only waits."""
+    import socket
+
+    with socket.socket() as sock:      # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:           # rank 0's JSON line (and nothing else of ours) arrives here
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank child launch exited with {rc}", file=sys.stderr)
+    return rc
+
+
 # ------------------------------------------------------------------------------------------- main
+def stream_roofline(kernel_ms: float, B: int, N: int, Nsim: int):
+    """roofline block of the throughput engine's kernel for the `secondary` record: algorithmic bytes as for the headline
+    (SURVEY 8d), traffic from the committed PMC passes of the same workload scaled to this launch's step count."""
+    algo = bytes_per_mpc_step(N) * B * Nsim
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    traffic = src = None
+    for name in ("r03_stream_b4096_pmc.json", "r02_stream_b4096_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            k = next(v for kk, v in d.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v)
+            wl = d.get("workload", {"batch": 4096, "N": 100, "Nsim": 100})
+            if (wl["batch"], wl["N"]) == (B, N):
+                # bytes per IPM iteration are what the passes move; per launch they scale with the iteration count, which the
+                # profile records -- quoted per closed-loop step of the profiled run, times this launch's steps
+                traffic = float(k["hbm_bytes_per_launch"]) / wl["Nsim"] * Nsim
+                src = f"profiles/{name} ({wl['Nsim']} profiled steps scaled to {Nsim}; separate --pmc passes, 2*FETCH+WRITE)"
+                break
+        except (OSError, ValueError, KeyError, StopIteration):
+            continue
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "kernel": "mpc_stream_kernel<double>", "avg_launch_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": algo}
+
+
 def throughput_leg(eng, chain, args):
     """Secondary figure (NOT `value`): kernel rate of the throughput engine at batch 4096, N=100, 600 closed-loop steps,
     SQP_RTI (one work-queue launch after one warm-up launch of 60 steps), measured with HIP events like the roofline."""
@@ -180,7 +230,8 @@ def throughput_leg(eng, chain, args):
            "engine": "throughput (one wavefront per simulation, work-queue launch)" if geo["engine"] == 1 else "latency",
            "kernel_ms": ms, "kernel_steps_per_s": B * pb.Nsim / (ms * 1e-3),
            "mean_qp_iters_per_step": float(bufs["qp_iter"].double().mean().item()),
-           "solver_failures": int((bufs["status"] != 0).sum().item())}
+           "solver_failures": int((bufs["status"] != 0).sum().item()),
+           "roofline": stream_roofline(ms, B, pb.N, pb.Nsim)}
     del bufs
     torch.cuda.empty_cache()
     return out
@@ -206,11 +257,14 @@ def main():
                     "one rank (rehearsal of the RCCL code path on a one-GPU box; launch under torch.distributed.run)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)      # plain `python bench.py --gpus N`: start the N ranks ourselves (no torch / HIP touched yet)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cpu_proc = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu_proc = start_cpu_baseline(args)      # before the first torch / HIP call of this process
 
     import torch
@@ -256,16 +310,20 @@ def main():
         """mpcb_run as BASELINE.md section 4 defines it; returns the host arrays on rank 0."""
         if args.kernel_only:
             eng.rollout(bufs, 0, pb.Nsim)
+            eng.sync()                        # mpcb_sync also reports a work-queue hand-off that did not complete
             return None
         eng.setup_packed(pb, params, robot)   # mpcb_setup: validate, derive model constants, upload the records (H2D)
         eng.rollout(bufs, 0, pb.Nsim)      # step0 = 0 restarts every simulation from its initial state
         local = dict(bufs)
         local["summary"] = eng.summary(bufs)
         if multi:
+            dmod.agree_ok(eng)                # mpcb_sync on every rank + one all-reduce of the verdict: all ranks raise together
             out = dmod.gather_to_root(local, sizes, gather_cache)   # product path of run_all: device tensors -> RCCL -> one D2H
             torch.cuda.current_stream().synchronize()         # a pass ends when this rank's results have left its buffers
             return out
-        return {k: dmod.to_host(v, host_bufs[k]) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
+        host = {k: dmod.to_host(v, host_bufs[k]) for k, v in local.items()}  # (a failed collective raises: the run exits non-zero)
+        eng.sync()                            # the copies have waited for the kernel; this reads the launch's error flag
+        return host
 
     for _ in range(args.warmup):
         one_pass()
@@ -341,4 +399,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

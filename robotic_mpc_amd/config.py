@@ -70,6 +70,42 @@ _ACCEPTED_NOOP = {
     "ext_fun_compile_flags", "regularize_method",   # (regularize_method: only NO_REGULARIZE passes the check below)
 }
 _QP_SOLVERS_EQUIVALENT = ("PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_HPIPM")
+# Attributes that DO exist on acados' AcadosOcpOptions and change the SQP / interior-point path.  The reference
+# forwards any existing attribute by setattr (simulator.py:129-135), so acados would honour them; the engine
+# implements exactly one value of each (acados' default, listed here) and REFUSES any other value instead of
+# handing back silently different iteration counts and trajectories.  Old and new (globalization_*) spellings.
+_FIXED_BEHAVIOUR = {
+    "alpha_min": 0.05, "globalization_alpha_min": 0.05,
+    "alpha_reduction": 0.7, "globalization_alpha_reduction": 0.7,
+    "nlp_solver_step_length": 1.0, "globalization_fixed_step_length": 1.0,
+    "line_search_use_sufficient_descent": 0, "globalization_line_search_use_sufficient_descent": 0,
+    "eps_sufficient_descent": 1e-4, "globalization_eps_sufficient_descent": 1e-4,
+    "full_step_dual": 0, "globalization_full_step_dual": 0,
+    "globalization_use_SOC": 0, "globalization_funnel_use_merit_fun_only": False,
+    "hpipm_mode": "BALANCE", "qp_solver_mu0": 0.0, "qp_solver_t0_init": 2,
+    "reg_epsilon": 1e-4, "reg_max_cond_block": 1e7, "reg_adaptive_eps": False, "reg_min_epsilon": 1e-8,
+    "cost_discretization": "EULER", "cost_scaling": None, "fixed_hess": 0,
+    "exact_hess_cost": 1, "exact_hess_dyn": 1, "exact_hess_constr": 1,
+    "nlp_solver_ext_qp_res": 0, "rti_phase": 0, "as_rti_iter": 1, "as_rti_level": 4, "rti_log_residuals": 0,
+    "rti_log_only_available_residuals": 0, "qp_solver_cond_block_size": None, "nlp_qp_tol_strategy": "FIXED_QP_TOL",
+    "with_adaptive_levenberg_marquardt": False, "adaptive_levenberg_marquardt_lam": 5.0,
+    "adaptive_levenberg_marquardt_mu_min": 1e-16, "adaptive_levenberg_marquardt_mu0": 1e-3,
+    "store_iterates": False, "timeout_max_time": 0.0, "qpscaling_scale_objective": "NO_OBJECTIVE_SCALING",
+    "qpscaling_scale_constraints": "NO_CONSTRAINT_SCALING", "tau_min": 0.0,
+    "sim_method_num_stages": 4, "sim_method_num_steps": 1, "sim_method_newton_iter": 3, "sim_method_jac_reuse": 0,
+    "collocation_type": "GAUSS_LEGENDRE", "time_steps": None, "shooting_nodes": None,
+}
+
+
+def _same_option_value(value, default) -> bool:
+    if default is None:
+        return value is None
+    if isinstance(default, str):
+        return value == default
+    try:
+        return float(value) == float(default)
+    except (TypeError, ValueError):
+        return False
 
 # The common synthetic base of SURVEY.md 8(d) (readme.md:27-43, surface_stats.ipynb cell 1).
 BASE_PARAMS: Dict[str, Any] = {
@@ -131,6 +167,10 @@ def resolve_solver_options(options: Optional[Mapping[str, Any]]) -> Dict[str, An
             qp_tols[key] = value
         elif key in out or key in _ACCEPTED_NOOP:
             out[key] = value
+        elif key in _FIXED_BEHAVIOUR:
+            if not _same_option_value(value, _FIXED_BEHAVIOUR[key]):
+                raise ValueError(f"solver option {key}={value!r}: acados would honour it (simulator.py:129-135) and it changes the "
+                                 f"SQP / QP iterations; the engine implements {key}={_FIXED_BEHAVIOUR[key]!r} only")
         else:
             warnings.warn(f"Warning: Unknown solver option '{key}'")
     # options that would change results and that the engine does not implement are errors, never ignored

@@ -170,6 +170,58 @@ def gather_to_root(local: Dict[str, object], sizes: List[int], cache: Optional[D
     return out
 
 
+def agree_ok(check=None, error: Optional[BaseException] = None) -> None:
+    """Cross-rank agreement before a collective: ``check`` (an engine -- its sync() is called -- or a callable) runs on
+    this rank, then one all-reduce (MIN) of the ok flags; if ANY rank failed every rank raises here, so no rank walks
+    into the gather alone and blocks.  ``error``: a failure this rank has already caught.  Without a process group it
+    is just the check."""
+    err = error
+    if err is None and check is not None:
+        try:
+            check.sync() if hasattr(check, "sync") else check()
+        except Exception as e:   # noqa: BLE001 -- reported below, on every rank
+            err = e
+    d = _dist()
+    if d is not None:
+        import torch
+
+        on_device = d.get_backend() == "nccl"
+        flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                            device=torch.device("cuda", local_device()) if on_device else torch.device("cpu"))
+        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        if int(flag.item()) == 0 and err is None:
+            raise RuntimeError(f"rank {d.get_rank()}: another rank failed before the results gather; stopping with it")
+    if err is not None:
+        raise err
+
+
+def complete_runner_output(local: Dict[str, object], cfgs: Sequence[Dict]) -> Dict[str, object]:
+    """Runner contract: 13 arrays [batch, ...] (engine.RESULT_FIELDS).  A runner written to the older 11-array contract
+    (no ``errors`` / ``plant_time``) is completed here: the task errors are recomputed from the pose / velocity logs
+    (analysis.compute_errors, the numpy mirror of simulator.py:265-344) and plant_time is zero.  Anything else that is
+    missing is reported up front instead of as a KeyError deep inside the gather."""
+    from .engine import RESULT_FIELDS
+
+    need = [n for n, _, _ in RESULT_FIELDS]
+    missing = [n for n in need if n not in local]
+    if not missing:
+        return local
+    fixable = {"errors", "plant_time"}
+    if not set(missing) <= fixable:
+        raise KeyError(f"runner output lacks {sorted(set(missing) - fixable)}; a runner returns {need} (+ optional 'summary')")
+    from . import analysis
+
+    out = dict(local)
+    if "plant_time" in missing:
+        out["plant_time"] = np.zeros(np.shape(to_host(local["solver_time"])))
+    if "errors" in missing:
+        pose, vel = to_host(local["ee_pose"]), to_host(local["ee_vel"])
+        out["errors"] = np.stack([analysis.errors_rows(analysis.compute_errors(pose[i], vel[i], c["coeffs"], c["t_ee"], c["px_ref"],
+                                                                               c["vy_ref"])) for i, c in enumerate(cfgs)]) \
+            if len(cfgs) else np.zeros((0, 7, pose.shape[-1]))
+    return out
+
+
 def to_host(v, out=None) -> np.ndarray:
     """Device tensor -> numpy through a pinned staging buffer (one DMA at PCIe rate); numpy stays numpy.  ``out``: a pinned
     host tensor of the same shape to copy into (caller-owned result buffer, reused from call to call)."""
@@ -217,16 +269,25 @@ def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Calla
         bounds = chunk_bounds(len(idxs), ws)
         lo, hi = bounds[me]
         mine = [resolved[i] for i in idxs[lo:hi]]
-        if key in tickets:
-            t = tickets.pop(key)
-            local = runner.collect(t) if t is not None else None
-            launch_more()
-        else:
-            local = runner(mine, chain_for(resolved[idxs[0]])) if mine else None
+        failure = None
+        try:
+            if key in tickets:
+                t = tickets.pop(key)
+                local = runner.collect(t) if t is not None else None
+                launch_more()
+            else:
+                local = runner(mine, chain_for(resolved[idxs[0]])) if mine else None
+            if local is not None:
+                local = complete_runner_output(local, mine)
+        except Exception as e:   # noqa: BLE001
+            if not (use_dist and _dist() is not None):
+                raise
+            failure, local = e, None
         if local is not None and "_kernel_ms" in local:
             kernel_ms += float(local.pop("_kernel_ms"))
         t0 = time.perf_counter()
         if use_dist and _dist() is not None:   # also a one-rank group: distributed=True asks for the collective path
+            agree_ok(error=failure) if failure is not None else agree_ok()   # every rank raises, or none: no lone rank in the gather
             if local is None:  # this rank got no simulation of the bucket: contribute empty arrays
                 local = _empty_like_bucket(resolved[idxs[0]], with_summary=True)
             elif "summary" not in local:

@@ -92,10 +92,31 @@ def save_results(path: str, names: Sequence[str], configs: Sequence[Dict], recor
 
 
 def load_archive(path: str) -> Dict[str, np.ndarray]:
+    """Format 2, or format 1 (written before `errors` / `plant_time` were logged): a v1 archive holds everything they
+    derive from, so the task errors are recomputed from its pose / velocity logs (analysis.compute_errors) and
+    plant_time is zero -- a grid search checkpointed by the older version still resumes."""
     with np.load(path, allow_pickle=False) as f:
-        if int(f["format_version"]) != FORMAT_VERSION:
-            raise ValueError(f"{path}: unsupported format version {int(f['format_version'])}")
-        return {k: f[k] for k in f.files}
+        ver = int(f["format_version"])
+        if ver not in (1, FORMAT_VERSION):
+            raise ValueError(f"{path}: unsupported format version {ver}")
+        arch = {k: f[k] for k in f.files}
+    if ver == 1:
+        from . import analysis
+        from .config import resolve_config
+
+        K = len(arch["names"])
+        T1 = arch["z"].shape[-1] if K else 1
+        err = np.zeros((K, 7, T1))
+        for i in range(K):
+            c = resolve_config(json.loads(str(arch["configs"][i])))
+            n = int(arch["nsim"][i])
+            e = analysis.compute_errors(arch["ee_pose"][i][:, :n + 1], arch["ee_vel"][i][:, :n + 1], c["coeffs"], c["t_ee"],
+                                        c["px_ref"], c["vy_ref"])
+            err[i, :, :n + 1] = analysis.errors_rows(e)
+        arch["errors"] = err
+        arch["plant_time"] = np.zeros_like(arch["solver_time"])
+        arch["format_version"] = np.int64(FORMAT_VERSION)
+    return arch
 
 
 def record_at(arch: Dict[str, np.ndarray], i: int) -> Dict[str, np.ndarray]:

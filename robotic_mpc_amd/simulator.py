@@ -305,12 +305,17 @@ class _EngineRunner:
 
     def collect(self, ticket):
         eng, stream, bufs, summary = ticket
-        stream.synchronize()
-        eng.sync()                      # (also reports a failed work-queue hand-off of the throughput engine)
+        try:
+            stream.synchronize()
+            eng.sync()                  # (also reports a failed work-queue hand-off of the throughput engine)
+            ms = eng.kernel_ms()
+        except Exception:
+            eng.close()                 # a handle whose launch failed is not recycled
+            raise
+        self._idle.append(eng)
         out = dict(bufs)
         out["summary"] = summary
-        out["_kernel_ms"] = eng.kernel_ms()
-        self._idle.append(eng)
+        out["_kernel_ms"] = ms
         return out
 
 

@@ -32,6 +32,38 @@ def test_baseline_names_the_bench_workload():
     assert bench.bytes_per_mpc_step(100) == 8 * (108 * 100 + 95)
 
 
+@pytest.mark.timeout(300)
+def test_plain_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start its ranks itself.  In a
+    container without a GPU both ranks get as far as creating the engine and fail loudly there (no CPU fallback); the
+    parent -- which never imports torch -- forwards the launcher's exit code."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-container check of the launch plumbing; the GPU run is test_self_launched_two_ranks_on_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--backend", "gloo", "--no-cpu-baseline", "--batch", "4", "--sim-time", "0.05"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode != 0
+    assert "2-rank child launch exited" in out.stderr
+    # the ranks themselves ran bench.py under torch.distributed.run (rank-tagged failure records), up to the device
+    assert "ChildFailedError" in out.stderr or "exitcode" in out.stderr
+    assert "needs one process per GPU" not in out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_self_launched_two_ranks_on_one_gpu():
+    """The same path on the GPU box: two gloo ranks sharing the one GPU, started by bench.py itself; rank 0 prints ONE
+    line carrying n_gpus = 2, the whole-job value and the cpu_baseline (N > 1 lines carry it too)."""
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--batch", "32", "--sim-time", "0.3")
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert abs(r["value"] - 2 * 32 * 30 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    assert r["cpu_baseline"] and r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
+    assert "gather" in r["config"]["timed_region"]
+
+
 @pytest.mark.gpu
 def test_bench_line_on_a_small_workload():
     # a reduced workload (the contract, not the number): 64 simulations, 60 closed-loop steps
@@ -54,3 +86,5 @@ def test_bench_line_on_a_small_workload():
     assert r["config"]["solver_failures"] == 0
     sec = r["secondary"]                     # extra record outside the timed region: the throughput geometry
     assert "4096" in sec["workload"] and sec["engine"].startswith("throughput") and sec["kernel_steps_per_s"] > 0 and sec["solver_failures"] == 0
+    srf = sec["roofline"]                    # the throughput kernel's own roofline block
+    assert srf["bound"] == "hbm" and abs(srf["frac"] - srf["achieved"] / srf["peak"]) < 1e-12 and "mpc_stream_kernel" in srf["kernel"]

@@ -57,3 +57,114 @@ def test_two_rank_gloo_sharded_equals_single(tmp_path, orc):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+# ------------------------------------------------------------------------------------------- 8 ranks
+def _worker8(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS="1")
+    import torch
+    import torch.distributed as dist
+
+    torch.set_num_threads(1)
+    import helpers as hp
+    from robotic_mpc_amd import SimulationManager, base_params, distributed as dmod, packing
+
+    class RaggedOracle:
+        """oracle runner that also takes merged (ragged) buckets, like the engine runner does"""
+        supports_ragged = True
+
+        def __call__(self, cfgs, chain):
+            return hp.oracle_runner(cfgs, chain)
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = False
+    try:
+        old = packing.RAGGED_MIN_BATCH
+        packing.RAGGED_MIN_BATCH = 2            # 3 horizons x 6 = 18 sims / 8 ranks >= 2 each: merged into ONE ragged bucket
+        m = SimulationManager(base_params(prediction_horizon=4, simulation_time=0.03), runner=RaggedOracle())
+        m.grid_search({"prediction_horizon": [3, 4, 6], "w_qddot": [0.02, 0.05, 0.08], "w_u": [0.01, 0.001]})   # 18 RTI sims
+        m.add_manual("sqp_a", {"solver_options": {"nlp_solver_type": "SQP", "nlp_solver_max_iter": 3}})         # bucket of 2 (< world)
+        m.add_manual("sqp_b", {"solver_options": {"nlp_solver_type": "SQP", "nlp_solver_max_iter": 3}, "w_u": 0.02})
+        resolved = [__import__("robotic_mpc_amd").resolve_config(s["config"]) for s in m.simulations]
+        buckets = dmod.group_buckets(resolved, world, True)
+        keys = list(buckets)
+        assert len(keys) == 2 and keys[0][0] == "ragged", keys
+        ragged = buckets[keys[0]]
+        assert sorted(ragged) == list(range(18))
+        bounds = dmod.chunk_bounds(18, world)
+        assert [hi - lo for lo, hi in bounds] == [3, 3, 2, 2, 2, 2, 2, 2] and bounds[0][0] == 0 and bounds[-1][1] == 18
+        # every rank's contiguous shard of the ragged bucket starts with its longest horizon (dispatched first) and the
+        # shards hold the same mix (round-robin deal of the horizon-sorted list)
+        lo, hi = bounds[rank]
+        mine = [resolved[i]["N"] for i in ragged[lo:hi]]
+        assert mine == sorted(mine, reverse=True), mine
+        assert dmod.chunk_bounds(2, world) == [(0, 1), (1, 2)] + [(2, 2)] * 6      # ranks 2..7 get nothing of the SQP bucket
+        res = m.run_all(distributed=True)
+        packing.RAGGED_MIN_BATCH = old
+        if rank == 0:
+            single = m.run_all(distributed=False)
+            assert [r["name"] for r in res] == [r["name"] for r in single] and len(res) == 20
+            for a, b in zip(res, single):
+                for k in ("q", "qdot", "u", "ee_pose"):
+                    assert np.array_equal(a["data"][k], b["data"][k]), (a["name"], k)
+                assert a["summary"]["weighted_rmse"] == b["summary"]["weighted_rmse"]
+                assert np.array_equal(a["simulator"].qp_iter, b["simulator"].qp_iter)
+            open(os.path.join(outdir, "ok8"), "w").write("ok")
+        else:
+            assert res == []
+        ok = True
+    finally:
+        if ok:                        # after a failure: no barrier (the other ranks may be gone) -- exit non-zero instead
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_gloo_ragged_merge_and_small_buckets(tmp_path, orc):
+    """The sharding the driver's 8-GPU run takes, on 8 gloo ranks: chunk bounds, one ragged bucket dealt over the ranks,
+    a bucket smaller than the world (six ranks contribute empty shards to its gather), sharded == unsharded bit for bit."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert (tmp_path / "ok8").exists()
+
+
+# ------------------------------------------------------------------------------------------- failure on one rank (ADVICE r2)
+def _worker_fail(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    import helpers as hp
+    from robotic_mpc_amd import SimulationManager, base_params
+
+    def runner(cfgs, chain):
+        if rank == 1:
+            raise RuntimeError("hand-off failed on this rank")      # what eng.sync() raises after a failed launch
+        return hp.oracle_runner(cfgs, chain)
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = SimulationManager(base_params(prediction_horizon=4, simulation_time=0.03), runner=runner)
+    m.sweep("w_qddot", [0.02, 0.05, 0.08, 0.1])
+    try:
+        m.run_all(distributed=True)
+    except RuntimeError as e:
+        # rank 1 raises its own error, rank 0 is told by the all-reduce in front of the gather: nobody blocks in it
+        open(os.path.join(outdir, f"raised{rank}"), "w").write(str(e))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_failure_on_one_rank_stops_every_rank_before_the_gather(tmp_path, orc):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker_fail, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert "hand-off failed" in (tmp_path / "raised1").read_text()
+    assert "another rank failed" in (tmp_path / "raised0").read_text()

@@ -45,6 +45,32 @@ def test_config_validation_mirrors_simulator_signature():
     assert r["coeffs"][0] == -0.3 and r["coeffs"][1] == 0.15
 
 
+def test_result_changing_acados_options_are_refused_not_ignored():
+    from robotic_mpc_amd import config
+
+    """simulator.py:129-135 sets ANY attribute that exists on AcadosOcpOptions, so acados would honour
+    alpha_min, full_step_dual, hpipm_mode ...; the engine implements their default only: a non-default value
+    raises, the default is accepted silently, and names acados does not know keep the reference's warning."""
+    cfg = _base()
+    rti = {"nlp_solver_type": "SQP_RTI"}
+    for key, bad in [("alpha_min", 0.01), ("alpha_reduction", 0.5), ("nlp_solver_step_length", 0.5),
+                     ("line_search_use_sufficient_descent", 1), ("eps_sufficient_descent", 1e-2), ("full_step_dual", 1),
+                     ("globalization_use_SOC", 1), ("hpipm_mode", "SPEED"), ("hpipm_mode", "ROBUST"), ("qp_solver_mu0", 10.0),
+                     ("qp_solver_t0_init", 0), ("cost_discretization", "INTEGRATOR"), ("globalization_alpha_min", 0.2),
+                     ("globalization_full_step_dual", 1), ("as_rti_level", 3), ("with_adaptive_levenberg_marquardt", True)]:
+        with pytest.raises(ValueError, match=key):
+            config.resolve_config({**cfg, "solver_options": {**rti, key: bad}})
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r = config.resolve_config({**cfg, "solver_options": {**rti, "alpha_min": 0.05, "alpha_reduction": 0.7, "hpipm_mode": "BALANCE",
+                                                             "full_step_dual": 0, "nlp_solver_step_length": 1.0, "qp_solver_mu0": 0}})
+        assert not w and r["solver_type"] == config.SOLVER_RTI
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        config.resolve_config({**cfg, "solver_options": {**rti, "alpha_minimum": 0.01}})   # not an acados attribute
+        assert any("Unknown solver option 'alpha_minimum'" in str(x.message) for x in w)
+
+
 # ----------------------------------------------------------------------------- queueing
 def test_sweep_and_grid_search_semantics():
     from robotic_mpc_amd import SimulationManager
@@ -228,6 +254,61 @@ def test_results_archive_round_trip_and_resume(orc, tmp_path):
     assert set(("names", "configs", "keys", "nsim", "z", "u", "status", "residuals")) <= set(arch)
     r0 = results_io.load_results(ck)[0]
     assert r0["summary"]["num_failures"] >= 0 and r0["simulator"].simulation_model.z.shape[0] == 12
+
+
+def test_format_1_archive_and_11_array_runner_still_work(orc, tmp_path):
+    """an archive written before `errors` / `plant_time` were logged (format 1) still resumes -- the task errors
+    are recomputed from its logs -- and a custom runner written to the 11-array contract is completed, not a KeyError."""
+    from robotic_mpc_amd import SimulationManager, results_io
+
+    def old_runner(cfgs, chain):
+        out = hp.oracle_runner(cfgs, chain)
+        out.pop("errors"); out.pop("plant_time")
+        return out
+
+    base = _base()
+    m = SimulationManager(base, runner=old_runner)
+    m.grid_search({"w_qddot": [0.02, 0.05]})
+    res_old = m.run_all()
+    m_new = SimulationManager(base, runner=hp.oracle_runner)
+    m_new.grid_search({"w_qddot": [0.02, 0.05]})
+    res_new = m_new.run_all()
+    for a, b in zip(res_old, res_new):
+        for k in ("rmse_e1", "itse_e5", "weighted_rmse", "total_sqp_iterations", "max_kkt_residual"):   # (timings differ run to run)
+            assert a["summary"][k] == b["summary"][k]
+        for k in ("e1", "e5", "p_ee_y"):
+            np.testing.assert_array_equal(a["analysis"][k], b["analysis"][k])
+    with pytest.raises(KeyError, match="ee_vel"):
+        _queued(base, lambda c, ch: {k: v for k, v in hp.oracle_runner(c, ch).items() if k != "ee_vel"}).run_all()
+
+    ck = str(tmp_path / "v2.npz")
+    m_new.run_all(checkpoint=ck)
+    arch = dict(np.load(ck, allow_pickle=False))
+    v1 = {k: v for k, v in arch.items() if k not in ("errors", "plant_time")}
+    v1["format_version"] = np.int64(1)
+    ck1 = str(tmp_path / "v1.npz")
+    np.savez_compressed(ck1, **v1)
+    back = results_io.load_archive(ck1)
+    np.testing.assert_allclose(back["errors"], arch["errors"], rtol=0, atol=0)
+    assert not back["plant_time"].any()
+    calls = []
+    m3 = SimulationManager(base, runner=lambda c, ch: calls.append(len(c)) or hp.oracle_runner(c, ch))
+    m3.grid_search({"w_qddot": [0.02, 0.05, 0.1]})
+    out = m3.run_all(checkpoint=ck1)                 # resumes from the v1 file: only the new combination runs
+    assert sum(calls) == 1 and m3.last_run_info["n_resumed"] == 2
+    assert out[0]["summary"]["weighted_rmse"] == res_new[0]["summary"]["weighted_rmse"]
+    with pytest.raises(ValueError, match="unsupported format version 3"):
+        v1["format_version"] = np.int64(3)
+        np.savez_compressed(ck1, **v1)
+        results_io.load_archive(ck1)
+
+
+def _queued(base, runner):
+    from robotic_mpc_amd import SimulationManager
+
+    m = SimulationManager(base, runner=runner)
+    m.sweep("w_qddot", [0.02])
+    return m
 
 
 def test_runner_with_submit_collect_launches_all_buckets_first(orc):
