@@ -267,6 +267,61 @@ struct Engine {
         const int ch = (ex.smem().pool_n - halo_doubles) / per_stage;
         return ex.uni(imax(1, imin(ch, ex.smem().n_hor + 1)));
     }
+    MPC_HD int chunk_len_in(int budget, int per_stage, int halo_doubles) const
+    {
+        const int ch = (budget - halo_doubles) / per_stage;
+        return ex.uni(imax(1, imin(ch, ex.smem().n_hor + 1)));
+    }
+
+    // =========================================================================== LDS-resident factor
+    // When the horizon is short enough (N <= ~125 with the whole pool of a CU), the part of the Riccati factor the
+    // three solve sweeps read -- K (72), R~^-1 h_u (6), e (12), p (12) per stage -- stays in LDS from the factorisation
+    // sweep to the final forward sweep of the same interior-point iteration and never travels through HBM.  With the
+    // whole horizon on chip the two vector recursions (dx forward, p backward) are no longer stage-by-stage chains on
+    // one wavefront: the horizon is cut into J = RS_GROUPS chunks of L transitions, one 16-lane group each;
+    //   pass 1: every group runs its chunk from a zero boundary value,
+    //   pass 2: one group walks the J chunk boundaries with the chunk transition matrices Phi_c = Acl_{t-1} ... Acl_s
+    //           (12x12, accumulated for free by an idle wavefront while the factorisation sweep runs),
+    //   pass 3: every group runs its chunk again from its true boundary value.
+    // 2 L + J steps instead of N (30 instead of 100 at N = 100, four wavefronts).  Everything else of the sweeps is
+    // item-parallel (lane <-> (stage, component)) with its operands loaded straight from HBM into registers, issued
+    // before the recursion so that their latency runs under it.
+    struct ResMap {
+        double *K, *VH, *E, *P, *PHI;   // persistent: [NS][72], [NS][6], [NS][12], [NS][12], [J][144]
+        double *scr;                    // scratch below them (fact: chunk buffers; sweeps: dx / gt / w / hand-over slots)
+        int scr_n, L;
+    };
+    static constexpr int RS_GROUPS = (NT / 16) < 16 ? (NT / 16) : 16;
+    static constexpr int RS_ROUNDS = 5;     // items a lane prefetches at a time (RS_ROUNDS * NT items per batch)
+    static constexpr int RS_PER_STAGE = 72 + 6 + 12 + 12;
+    MPC_HD ResMap res_map() const
+    {
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1, pool_n = ex.uni(ex.smem().pool_n);
+        const int persist = NS * RS_PER_STAGE + RS_GROUPS * 144;
+        ResMap m;
+        m.scr = ex.pool();
+        m.scr_n = pool_n - persist;
+        m.K = ex.pool() + m.scr_n;
+        m.VH = m.K + (size_t)NS * 72;
+        m.E = m.VH + (size_t)NS * 6;
+        m.P = m.E + (size_t)NS * 12;
+        m.PHI = m.P + (size_t)NS * 12;
+        m.L = (Nl + RS_GROUPS - 1) / RS_GROUPS;
+        return m;
+    }
+    MPC_HD bool resident_ok() const
+    {
+#ifdef MPCB_NO_RESIDENT
+        return false;
+#else
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1, pool_n = ex.uni(ex.smem().pool_n);
+        const int scr = pool_n - (NS * RS_PER_STAGE + RS_GROUPS * 144);
+        // scratch: the factorisation's double-buffered chunks (>= 6 stages) ; the corrector's gt (18) + w (12) + slots
+        return ex.uni(scr >= 4096 && scr >= NS * 30 + 2 * RS_GROUPS * 12 + 16);
+#endif
+    }
+    MPC_HD static double gld(const double *p) { return *(MPC_GLOBAL const double *)p; }
+    MPC_HD static void gst(double *p, double v) { *(MPC_GLOBAL double *)p = v; }
 
     // =========================================================================== NLP pass
     // One pass over the horizon that (optionally) applies the SQP/RTI step to the iterate
@@ -676,14 +731,20 @@ struct Engine {
         int oqq, oqv, ovv;           // packed offsets (tri) of the block's qq, qv, vv entries
     };
 
-    MPC_PASS void fact_pass()
+    // RES: the factor stays in LDS (see above): K, R~^-1 h_u, e, p go to the resident arrays, the chunk record and the
+    // HBM store shrink to [P | w | R~^-1] (126 of 228 columns), and the first background wavefront accumulates Phi_c.
+    template <bool RES>
+    MPC_PASS void fact_pass_t()
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WR = 78;  // G2 columns [O_GQ, O_RB+12): GQ 0, GV 30, GAM 36, GT 48, RB 66
-        const int CH = chunk_len(2 * (WR + W4), 2 * WR);
+        constexpr int WF = RES ? W4 - O_PM : W4;   // LDS factor record of a chunk
+        constexpr int FO = RES ? O_PM : 0;         // G4 column it starts at (`fac` below is biased by -FO: fac[O_*] works in both)
+        const ResMap rm = res_map();
+        const int CH = RES ? chunk_len_in(rm.scr_n, 2 * (WR + WF), 2 * WR) : chunk_len(2 * (WR + W4), 2 * WR);
         typename Ex::template PerLane<FactLane> fl;
         ex.seq([&](int lane) {
             FactLane &f = fl.at(lane);
@@ -725,16 +786,17 @@ struct Engine {
         //   wavefronts 2+ fetch the inputs of chunk ci+1, write the finished factor of chunk ci-1 back
         // Two chunks in flight (inputs and factor double-buffered).
         int sb = 0;
-        const size_t buf = (size_t)(CH + 1) * WR + (size_t)CH * W4;
+        const size_t buf = (size_t)(CH + 1) * WR + (size_t)CH * WF;
         auto vr_of = [&](int ci) { return ex.pool() + (size_t)(ci & 1) * buf; };
         auto vf_of = [&](int ci) { return vr_of(ci) + (size_t)(CH + 1) * WR; };
         auto k1_of = [&](int ci) { return Nl - ci * CH; };
         typename Ex::template PerLane<double> pr;   // wavefront 1, lanes < 12: p_{k+1}[lane]
         typename Ex::template PerLane<double> tr, wr;
         typename Ex::template PerLane<D2> ab;       // wavefront 1, lanes < 12: (a12, a22) of the lane's joint
-        double b1r[6], b2r[6];
+        double b1r[6], b2r[6], a12r[6], a22r[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { b1r[i] = P.b1[i]; b2r[i] = P.b2[i]; }
+        for (int i = 0; i < 6; i++) { b1r[i] = P.b1[i]; b2r[i] = P.b2[i]; a12r[i] = P.a12[i]; a22r[i] = P.a22[i]; }
+        typename Ex::template PerLane<double> phi[12];   // RES, first background wavefront: row `lane` of Phi_c
         int vcur = 0;
         // vector recursion of chunk ci (stages k1c..k0c) -- runs on ONE wavefront (Ex::sub phases)
         auto vec_sweep = [&](int ci) {
@@ -744,9 +806,11 @@ struct Engine {
             for (int k = k1c; k >= k0c; k--) {
                 const double *ric = vr + (size_t)(k - klc) * WR;
                 const double *gt = ric + 48, *rbv = ric + 66;
-                double *fac = vf + (size_t)(k - k0c) * W4;
+                double *fac = vf + (size_t)(k - k0c) * WF - FO;
+                double *kk = RES ? rm.K + (size_t)k * 72 : fac + O_K, *vhp = RES ? rm.VH + (size_t)k * 6 : fac + O_VH;
+                double *ep = RES ? rm.E + (size_t)k * 12 : fac + O_E, *pvp = RES ? rm.P + (size_t)k * 12 : fac + O_PV;
                 // P_{k+1}: next row of this chunk, or the lowest row of the chunk above (other buffer, intact)
-                const double *Pn = (k < k1c ? fac + W4 : vf_of(ci + 1)) + O_PM;
+                const double *Pn = (k < k1c ? fac + WF : vf_of(ci + 1) - FO) + O_PM;
                 const int vnxt = vcur ^ 1;
                 ex.await(&sm.prog, Nl - k);   // the matrices of stage k are in LDS
                 if (k == Nl) {
@@ -754,12 +818,12 @@ struct Engine {
                         if (lane < NX) {
                             const double v = gt[6 + lane];
                             pr.at(lane) = v; ex.share(sm.pv[vcur], lane, v);
-                            fac[O_PV + lane] = v; fac[O_WV + lane] = 0.0; fac[O_E + lane] = 0.0;
+                            pvp[lane] = v; fac[O_WV + lane] = 0.0; ep[lane] = 0.0;
                             const int j = lane % 6;
                             D2 c2; c2.x = P.a12[j]; c2.y = P.a22[j];
                             ab.at(lane) = c2;
                         }
-                        if (lane < NU) fac[O_VH + lane] = 0.0;
+                        if (lane < NU) vhp[lane] = 0.0;
                     });
                     continue;
                 }
@@ -791,10 +855,10 @@ struct Engine {
                         double pj = gt[6 + j] + (j < 6 ? t : c2.x * oq + c2.y * t);
                         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                        for (int m = 0; m < 6; m += 2) { s0 += fac[O_K + m * 12 + j] * hu[m]; s1 += fac[O_K + (m + 1) * 12 + j] * hu[m + 1]; }
+                        for (int m = 0; m < 6; m += 2) { s0 += kk[m * 12 + j] * hu[m]; s1 += kk[(m + 1) * 12 + j] * hu[m + 1]; }
                         pj -= s0 + s1;
                         pr.at(lane) = pj; ex.share(sm.pv[vnxt], lane, pj);
-                        fac[O_PV + j] = pj;
+                        pvp[j] = pj;
                         fac[O_WV + j] = w;
                         // what the forward sweep needs of h_u: R~^-1 h_u and e = rb - B R~^-1 h_u
                         const int i6 = j < 6 ? j : j - 6;
@@ -802,8 +866,8 @@ struct Engine {
 #pragma unroll
                         for (int m = 0; m < 6; m += 2) { v0 += fac[O_RI + i6 * 6 + m] * hu[m]; v1 += fac[O_RI + i6 * 6 + m + 1] * hu[m + 1]; }
                         const double vh = v0 + v1;
-                        if (j < 6) fac[O_VH + j] = vh;
-                        fac[O_E + j] = rbv[j] - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
+                        if (j < 6) vhp[j] = vh;
+                        ep[j] = rbv[j] - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
                     }
                 });
                 vcur = vnxt;
@@ -822,7 +886,8 @@ struct Engine {
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
-                double *fac = vf + (size_t)(k - k0) * W4;
+                double *fac = vf + (size_t)(k - k0) * WF - FO;
+                double *kk = RES ? rm.K + (size_t)k * 72 : fac + O_K;   // K_k: the resident array, or the chunk record
                 const double *gam = ric + 36;
                 if (k == Nl) {
                     // terminal stage: no cost, no bounds -> P_N = lm I (0 without levenberg_marquardt) ; R~, S~ of stage N-1
@@ -841,6 +906,7 @@ struct Engine {
                     continue;
                 }
                 // ---- B: LDL' (right-looking) + one right-hand side per lane
+#ifndef MPCB_DIAG_NO_B
                 ex.seq([&](int lane) {
                     const double *St = sm.St2[sb];
                     double A_[6][6];
@@ -851,6 +917,9 @@ struct Engine {
                     double dinv[6];
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
+#ifdef MPCB_DIAG_NO_LDL
+                        dinv[j] = A_[j][j]; continue;
+#endif
                         dinv[j] = fast_rcp(A_[j][j]);
                         double lj[6];
 #pragma unroll
@@ -883,15 +952,20 @@ struct Engine {
                         }
                         if (lane < 12) {
 #pragma unroll
-                            for (int i = 0; i < 6; i++) { fac[O_K + i * 12 + lane] = x[i]; sm.Kf[i * 12 + lane] = x[i]; }
+                            for (int i = 0; i < 6; i++) kk[i * 12 + lane] = x[i];
                         } else {
 #pragma unroll
                             for (int i = 0; i < 6; i++) fac[O_RI + i * 6 + (lane - 12)] = x[i];
                         }
                     }
                 });
+#endif
                 // ---- CA: P_k block, then R~/S~ of stage k-1
                 ex.seq([&](int lane) {
+#ifdef MPCB_DIAG_NO_CA
+                    if (lane == 0) ex.post(&sm.prog, Nl - k);
+                    return;
+#endif
                     if (lane < 36) {
                         FactLane &f = fl.at(lane);
                         if (k > 0) {
@@ -901,7 +975,7 @@ struct Engine {
 #pragma unroll
                             for (int m = 0; m < 6; m++) {
                                 sa[m] = St[m * 12 + f.a]; sva[m] = St[m * 12 + 6 + f.a];
-                                kb[m] = sm.Kf[m * 12 + f.b]; kvb[m] = sm.Kf[m * 12 + 6 + f.b];
+                                kb[m] = kk[m * 12 + f.b]; kvb[m] = kk[m * 12 + 6 + f.b];
                             }
                             const double ga0 = gq[f.a], ga1 = gq[6 + f.a], ga2 = gq[12 + f.a], ga3 = gq[18 + f.a], ga4 = gq[24 + f.a];
                             const double gb0 = gq[f.b], gb1 = gq[6 + f.b], gb2 = gq[12 + f.b], gb3 = gq[18 + f.b], gb4 = gq[24 + f.b];
@@ -929,14 +1003,56 @@ struct Engine {
                 sb ^= 1;
             }
             }, [&]() {
+#ifndef MPCB_DIAG_NO_VEC
                 vec_sweep(ci);   // wavefront 1: vector recursion of this chunk, one stage behind the matrices
+#endif
             }, [&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), ex.smem().w.G2, nkl, nk1, lane);
-                if (ci > 0) copy_lanes<W4, 0, W4, W4, false, NL>(vf_of(ci - 1), ex.smem().w.G4, pk0, pk1, lane);
+                if (ci > 0) copy_lanes<WF, FO, W4, WF, false, NL>(vf_of(ci - 1), ex.smem().w.G4, pk0, pk1, lane);
+                if constexpr (RES) {
+                    // copies issued: the first background wavefront follows the recursion and accumulates the chunk
+                    // transition matrix Phi_c <- Phi_c Acl_k (lane i < 12 holds row i in registers), k descending
+#ifndef MPCB_DIAG_NO_PHI
+                    if (lane < WAVE) {
+                        const int L = rm.L;
+                        for (int k = imin(k1, Nl - 1); k >= k0; k--) {
+                            ex.await(&sm.prog, Nl - k);
+                            const double *kk = rm.K + (size_t)k * 72;
+                            const int c = k / L;
+                            const bool first = ex.uni(k == imin((c + 1) * L, Nl) - 1), last = ex.uni(k == c * L);
+                            // K_k is the same for every lane: ONE 16-byte LDS read per lane (lanes 0..35 cover the 72 entries),
+                            // then each entry reaches the arithmetic as a scalar (v_readlane) -- 36 broadcast reads per stage
+                            // here held up the recursion wavefront's own LDS reads (measured: +8 us per sweep)
+                            const D2 kv2 = reinterpret_cast<const D2 *>(kk)[(lane & (WAVE - 1)) < 36 ? (lane & (WAVE - 1)) : 0];
+                            auto Kat = [&](int idx) { return ex.lane_value(kk, idx, (idx & 1) ? kv2.y : kv2.x, idx >> 1); };
+                            {
+                                double ph[12], g[6], nw[12];
+#pragma unroll
+                                for (int j = 0; j < 12; j++) ph[j] = first ? (j == lane ? 1.0 : 0.0) : phi[j].at(lane);
+#pragma unroll
+                                for (int m = 0; m < 6; m++) g[m] = ph[m] * b1r[m] + ph[6 + m] * b2r[m];
+#pragma unroll
+                                for (int j = 0; j < 6; j++) {
+                                    double s0 = ph[j], s1 = a12r[j] * ph[j] + a22r[j] * ph[6 + j];
+#pragma unroll
+                                    for (int m = 0; m < 6; m++) { s0 -= g[m] * Kat(m * 12 + j); s1 -= g[m] * Kat(m * 12 + 6 + j); }
+                                    nw[j] = s0; nw[6 + j] = s1;
+                                }
+#pragma unroll
+                                for (int j = 0; j < 12; j++) phi[j].at(lane) = nw[j];
+                                if (last && lane < NX) {
+#pragma unroll
+                                    for (int j = 0; j < 12; j++) rm.PHI[(size_t)c * 144 + lane * 12 + j] = nw[j];
+                                }
+                            }
+                        }
+                    }
+#endif
+                }
             });
             PROF_ADD(PF_SEQ_FACT, ts);
-            if (k0 == 0) store_rect<W4, 0, W4>(vf, ex.smem().w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
+            if (k0 == 0) copy_rect<WF, FO, W4, WF, false>(vf, ex.smem().w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
         }
         PROF_ADD(PF_FACT, t0);
     }
@@ -1355,6 +1471,390 @@ struct Engine {
         return alpha;
     }
 
+    // =========================================================================== resident sweeps
+    // Chunk-parallel affine recursion over the resident factor (see "LDS-resident factor" above).
+    //   FWD:  dx_{k+1} = Acl_k dx_k + e_k,  dx_0 = 0                       -> vec[k] = dx_k, k = 0..N
+    //   BWD:  p_k = c_k + Acl_k' p_{k+1},   p_N = c_N (vec holds c on entry) -> vec[k] = p_k, in place
+    // with Acl_k = A - B K_k.  `xch`, `xs`: [RS_GROUPS][12] hand-over slots / chunk boundary values (scratch).
+    // Ends with every lane's LDS writes issued, NOT with a barrier.
+    template <bool FWD>
+    MPC_HD void rs_recursion(const ResMap &rm, double *vec, double *xch, double *xs)
+    {
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), L = rm.L;
+        const int Jused = (Nl + L - 1) / L;
+        typename Ex::template PerLane<double> z;
+        typename Ex::template PerLane<D2> ab, bb;
+        double b1r[6], b2r[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) { b1r[m] = P.b1[m]; b2r[m] = P.b2[m]; }
+        // one step of chunk c = lane / 16 on transition k: reads the group's vector from its slot, leaves the new one in z
+        auto step_compute = [&](int lane, int k) {
+            const int c = lane >> 4, i = lane & 15, i6 = i < 6 ? i : i - 6;
+            const double *zz = xch + c * 12;
+            const D2 a = ab.at(lane), b = bb.at(lane);
+            // the group's vector as six 16-byte reads; the lane's own entries by their own (lane-addressed) reads: a
+            // register array indexed by a lane-dependent value becomes a chain of 2 x 11 v_cndmask per access
+            const D2 *z2 = reinterpret_cast<const D2 *>(zz);
+            double zv[12];
+#pragma unroll
+            for (int j = 0; j < NX; j += 2) { const D2 t = z2[j >> 1]; zv[j] = t.x; zv[j + 1] = t.y; }
+            if (FWD) {
+                const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)k * 72 + i6 * 12);
+                const double own = zz[i], ov = zz[i6 + 6], ek = rm.E[(size_t)k * 12 + i];
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; j += 2) { const D2 t = kr[j >> 1]; s0 += t.x * zv[j]; s1 += t.y * zv[j + 1]; }
+                const double kd = s0 + s1;
+                z.at(lane) = ek + (i < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+            } else {
+                const double *kc = rm.K + (size_t)k * 72 + i;   // column i of K_k
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 6; m += 2) {
+                    acc0 += kc[m * 12] * (b1r[m] * zv[m] + b2r[m] * zv[6 + m]);
+                    acc1 += kc[(m + 1) * 12] * (b1r[m + 1] * zv[m + 1] + b2r[m + 1] * zv[7 + m]);
+                }
+                const double mine = zz[i], oq = zz[i6];
+                const double at = i < 6 ? mine : a.x * oq + a.y * mine;
+                z.at(lane) = vec[(size_t)k * 12 + i] + (at - (acc0 + acc1));
+            }
+        };
+        // local sweeps of all chunks; STORE: pass 3 (writes the results), else pass 1 (zero boundary value)
+        auto sweep = [&](auto store_tag) {
+            constexpr bool STORE = decltype(store_tag)::value;
+            ex.wpar([&](int lane) {
+                const int c = lane >> 4, i = lane & 15;
+                if (lane < RS_GROUPS * 16 && i < NX) {
+                    const double v = STORE ? xs[c * 12 + i] : 0.0;
+                    z.at(lane) = v;
+                    xch[c * 12 + i] = v;
+                    if (STORE && FWD && c < Jused) vec[(size_t)c * L * 12 + i] = v;   // dx at the chunk's first stage
+                }
+            });
+            for (int t = 0; t < L; t++) {
+                ex.wpar([&](int lane) {
+                    const int c = lane >> 4, i = lane & 15;
+                    const int ks = c * L, ke = imin(ks + L, Nl);
+                    const int k = FWD ? ks + t : ke - 1 - t;
+                    if (lane < RS_GROUPS * 16 && i < NX && k >= ks && k < ke) step_compute(lane, k);
+                });
+                ex.wpar([&](int lane) {
+                    const int c = lane >> 4, i = lane & 15;
+                    const int ks = c * L, ke = imin(ks + L, Nl);
+                    const int k = FWD ? ks + t : ke - 1 - t;
+                    if (lane < RS_GROUPS * 16 && i < NX && k >= ks && k < ke) {
+                        const double v = z.at(lane);
+                        xch[c * 12 + i] = v;
+                        if (STORE) {
+                            // FWD: v = dx_{k+1}; the first stage of the next chunk belongs to that chunk (boundary value)
+                            if (FWD) { if (k + 1 < ke || k + 1 == Nl) vec[(size_t)(k + 1) * 12 + i] = v; }
+                            else vec[(size_t)k * 12 + i] = v;
+                        }
+                    }
+                });
+            }
+        };
+        ex.wpar([&](int lane) {
+            const int j6 = (lane & 15) % 6;
+            D2 a; a.x = P.a12[j6]; a.y = P.a22[j6]; ab.at(lane) = a;
+            D2 b; b.x = P.b1[j6]; b.y = P.b2[j6]; bb.at(lane) = b;
+        });
+        sweep(std::false_type{});
+        ex.barrier();
+        // pass 2: chunk boundary values, one group (wavefront 0, lanes < 12); y_c = the slot pass 1 left
+        {
+            typename Ex::template PerLane<double> xr;
+            int cur = 0;
+            ex.seq([&](int lane) {
+                const double v = (!FWD && lane < NX) ? vec[(size_t)Nl * 12 + lane] : 0.0;
+                xr.at(lane) = v;
+                if (lane < NX) ex.share(sm.pv[cur], lane, v);
+            });
+            for (int cc = 0; cc < Jused; cc++) {
+                const int c = FWD ? cc : Jused - 1 - cc, nxt = cur ^ 1;
+                ex.seq([&](int lane) {
+                    // this chunk's row (column) of Phi and y first: their latency runs under the gather
+                    const int lc = lane < NX ? lane : 0;
+                    const double *ph = rm.PHI + (size_t)c * 144;
+                    double pr[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) pr[j] = FWD ? ph[lc * 12 + j] : ph[j * 12 + lc];
+                    const double y = xch[c * 12 + lc];
+                    const double own = xr.at(lane);
+                    double xv[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) xv[j] = ex.gather(sm.pv[cur], j, own);
+                    double s0 = y, s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; j += 2) { s0 += pr[j] * xv[j]; s1 += pr[j + 1] * xv[j + 1]; }
+                    const double v = s0 + s1;
+                    xr.at(lane) = v;
+                    if (lane < NX) { xs[c * 12 + lane] = own; ex.share(sm.pv[nxt], lane, v); }
+                });
+                cur = nxt;
+            }
+        }
+        ex.barrier();
+        sweep(std::true_type{});
+    }
+
+    // Forward sweep on the resident factor: dx by rs_recursion, then item-parallel (lane <-> (stage, bounded component)):
+    // du = -(R~^-1 h_u + K dx), dt, dlam (HPIPM compute_lam_t), largest feasible step, centering sums; the final sweep
+    // also dpi_{k-1} = p_k + P_k dx_k and the whole Newton step to HBM.  Leaves alpha, S0, S1, S2 in sm.cen[0..3].
+    template <bool AFFINE>
+    MPC_PASS double fwd_resident()
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        const ResMap rm = res_map();
+        double *X = rm.scr, *xch = X + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
+        const int items = NS * NB;
+        constexpr int R = RS_ROUNDS;
+        double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
+        typename Ex::template PerLane<double> ld[R][8];
+        typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
+        // operands of a batch of items: lam, t (G1), rd, rm (G3), lower | upper -- unconditional, clamped
+        auto issue = [&](int base) {
+            ex.wpar([&](int lane) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
+                    const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
+                    ld[r][0].at(lane) = gld(g1 + O_QLAM + j); ld[r][1].at(lane) = gld(g1 + O_QLAM + 12 + j);
+                    ld[r][2].at(lane) = gld(g1 + O_QT + j);   ld[r][3].at(lane) = gld(g1 + O_QT + 12 + j);
+                    ld[r][4].at(lane) = gld(g3 + O_RD + j);   ld[r][5].at(lane) = gld(g3 + O_RD + 12 + j);
+                    ld[r][6].at(lane) = gld(g3 + O_RM + j);   ld[r][7].at(lane) = gld(g3 + O_RM + 12 + j);
+                }
+                if (base == 0) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; }
+            });
+        };
+        issue(0);
+        PROF_T0(ts);
+        rs_recursion<true>(rm, X, xch, xs);
+        ex.barrier();
+        PROF_ADD(PF_SEQ_FWD, ts);
+        for (int base = 0; base < items; base += R * NT) {
+            if (base > 0) issue(base);
+            ex.wpar([&](int lane) {
+                double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = base + r * NT + lane;
+                    if (e < items) {
+                        const int k = e / NB, j = e - k * NB;
+                        const double *dxk = X + (size_t)k * 12;
+                        double *g3 = G3 + (size_t)k * W3;
+                        double dv;
+                        if (j < 6) {
+                            dv = 0.0;
+                            if (k < Nl) {
+                                const double *kr = rm.K + (size_t)k * 72 + j * 12;
+                                double s0 = rm.VH[(size_t)k * 6 + j], s1 = 0.0;
+#pragma unroll
+                                for (int i = 0; i < NX; i += 2) { s0 += kr[i] * dxk[i]; s1 += kr[i + 1] * dxk[i + 1]; }
+                                dv = -(s0 + s1);
+                            }
+                            if (!AFFINE) gst(g3 + O_DW + j, dv);          // du_k (stage N has no input: 0)
+                        } else {
+                            dv = dxk[j - 6];
+                        }
+                        if (!AFFINE) gst(g3 + O_DW + 6 + j, dxk[j]);      // dx_k, all twelve components
+                        const bool hc = has_comp(Nl, k, j);
+                        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                        const double ll = ld[r][0].at(lane), lu = ld[r][1].at(lane), tl = ld[r][2].at(lane), tu = ld[r][3].at(lane);
+                        const double rdl = ld[r][4].at(lane), rdu = ld[r][5].at(lane), rml = ld[r][6].at(lane), rmu = ld[r][7].at(lane);
+                        double dtl = 0, dll = 0, dtu = 0, dlu = 0;
+                        if (blo) {
+                            dtl = dv + rdl;
+                            dll = -(rml + ll * dtl) * fast_rcp(tl);
+                            if (dll < 0 && ll + al * dll < 0) al = -ll * fast_rcp(dll);
+                            if (dtl < 0 && tl + al * dtl < 0) al = -tl * fast_rcp(dtl);
+                            a0 += ll * tl; a1 += ll * dtl + tl * dll; a2 += dll * dtl;
+                        }
+                        if (bhi) {
+                            dtu = -dv + rdu;
+                            dlu = -(rmu + lu * dtu) * fast_rcp(tu);
+                            if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
+                            if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
+                            a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
+                        }
+                        gst(g3 + O_DLAM + j, dll); gst(g3 + O_DLAM + 12 + j, dlu);
+                        gst(g3 + O_DT + j, dtl);   gst(g3 + O_DT + 12 + j, dtu);
+                    }
+                }
+                r_al.at(lane) = al; r_a0.at(lane) = a0; r_a1.at(lane) = a1; r_a2.at(lane) = a2;
+            });
+            if (!AFFINE) {
+                // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1}): row j of the packed P_k from HBM
+                ex.wpar([&](int lane) {
+                    double pm[R][12];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
+                        const double *g4 = G4 + (size_t)k * W4 + O_PM;
+#pragma unroll
+                        for (int i = 0; i < NX; i++) pm[r][i] = gld(g4 + tri_sym(j, i));
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / NB, j = e - k * NB;
+                            const double *dxk = X + (size_t)k * 12;
+                            double v = 0.0;
+                            if (k >= 1) {
+                                double s0 = rm.P[(size_t)k * 12 + j], s1 = 0.0;
+#pragma unroll
+                                for (int i = 0; i < NX; i += 2) { s0 += pm[r][i] * dxk[i]; s1 += pm[r][i + 1] * dxk[i + 1]; }
+                                v = s0 + s1;
+                            }
+                            gst(G3 + (size_t)k * W3 + O_DPI + j, v);
+                        }
+                    }
+                });
+            }
+        }
+        ex.par([&](int lane) {
+            ex.put_min(sm.red[0], lane, r_al.at(lane)); ex.put_sum(sm.red[1], lane, r_a0.at(lane));
+            ex.put_sum(sm.red[2], lane, r_a1.at(lane)); ex.put_sum(sm.red[3], lane, r_a2.at(lane));
+        });
+        const double alpha = ex.get_min(sm.red[0]);
+        const double S0 = ex.get_sum(sm.red[1]), S1 = ex.get_sum(sm.red[2]), S2 = ex.get_sum(sm.red[3]);
+        ex.par([&](int lane) {
+            if ((lane & (WAVE - 1)) == 0) { sm.cen[0] = alpha; sm.cen[1] = S0; sm.cen[2] = S1; sm.cen[3] = S2; }
+        });
+        PROF_ADD(PF_FWD, t0);
+        return alpha;
+    }
+
+    // Centering corrector + backward solve on the resident factor (see corrector_bwd_pass for the algebra):
+    //   items (stage, component): rm, rebuilt gt -> LDS ; c_k -> resident p array ; rs_recursion (p in place) ;
+    //   items: h_u, R~^-1 h_u, e -> resident.  Only rm goes back to HBM.
+    MPC_PASS void corr_resident(double sigma_mu)
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        const ResMap rm = res_map();
+        double *GT = rm.scr, *RW = GT + (size_t)NS * 18, *xch = RW + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
+        const int items = NS * NB;
+        constexpr int R = RS_ROUNDS;
+        double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
+        // ---- rm, gt of every bounded component (+ w_k into LDS); gt of the velocity components is rg
+        for (int base = 0; base < items; base += R * NT) {
+            ex.wpar([&](int lane) {
+                double v[R][12];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
+                    const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
+                    v[r][0] = gld(g1 + O_QLAM + j); v[r][1] = gld(g1 + O_QLAM + 12 + j);
+                    v[r][2] = gld(g1 + O_QT + j);   v[r][3] = gld(g1 + O_QT + 12 + j);
+                    v[r][4] = gld(g3 + O_DLAM + j); v[r][5] = gld(g3 + O_DLAM + 12 + j);
+                    v[r][6] = gld(g3 + O_DT + j);   v[r][7] = gld(g3 + O_DT + 12 + j);
+                    v[r][8] = gld(g3 + O_RD + j);   v[r][9] = gld(g3 + O_RD + 12 + j);
+                    v[r][10] = gld(g3 + O_RG + j);
+                    v[r][11] = gld(G4 + (size_t)k * W4 + O_WV + j);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = base + r * NT + lane;
+                    if (e < items) {
+                        const int k = e / NB, j = e - k * NB;
+                        const bool hc = has_comp(Nl, k, j);
+                        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                        const double ll = v[r][0], lu = v[r][1], tl = v[r][2], tu = v[r][3];
+                        const double dll = v[r][4], dlu = v[r][5], dtl = v[r][6], dtu = v[r][7], rdl = v[r][8], rdu = v[r][9];
+                        double gt = v[r][10];
+                        const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
+                        const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
+                        gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
+                        gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                        GT[(size_t)k * 18 + j] = gt;
+                        RW[(size_t)k * 12 + j] = v[r][11];
+                        gst(G3 + (size_t)k * W3 + O_RM + j, rml); gst(G3 + (size_t)k * W3 + O_RM + 12 + j, rmu);
+                    }
+                }
+            });
+        }
+        ex.wpar([&](int lane) {
+            for (int e = lane; e < NS * 6; e += NT) {
+                const int k = e / 6, j = e - k * 6;
+                GT[(size_t)k * 18 + 12 + j] = gld(G3 + (size_t)k * W3 + O_RG + 12 + j);
+            }
+        });
+        ex.barrier();
+        // ---- c_k = gt_x + A' w - Kfb' (gt_u + B' w) -> resident p array (stage N: p_N = gt_x)
+        ex.wpar([&](int lane) {
+            for (int e = lane; e < items; e += NT) {
+                const int k = e / NX, j = e - k * NX;
+                const double *gt = GT + (size_t)k * 18, *w = RW + (size_t)k * 12, *kf = rm.K + (size_t)k * 72;
+                double vv = gt[6 + j];
+                if (k < Nl) {
+                    vv += (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
+#pragma unroll
+                    for (int m = 0; m < 6; m++) vv -= kf[m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
+                }
+                rm.P[(size_t)k * 12 + j] = vv;
+            }
+        });
+        ex.barrier();
+        // operands of the last phase (R~^-1 row, rb), issued before the recursion
+        typename Ex::template PerLane<double> ld[R][7];
+        auto issue = [&](int base) {
+            ex.wpar([&](int lane) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = imin(base + r * NT + lane, items - 1), k = e / NX, j = e - k * NX, i6 = j < 6 ? j : j - 6;
+                    const double *ri = G4 + (size_t)k * W4 + O_RI + i6 * 6;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) ld[r][m].at(lane) = gld(ri + m);
+                    ld[r][6].at(lane) = gld(G2 + (size_t)k * W2 + O_RB + j);
+                }
+            });
+        };
+        issue(0);
+        PROF_T0(ts);
+        rs_recursion<false>(rm, rm.P, xch, xs);
+        ex.barrier();
+        PROF_ADD(PF_SEQ_BWD, ts);
+        // ---- h_u,k = gt_u + B'(p_{k+1} + w_k) ; R~^-1 h_u and e = rb - B R~^-1 h_u for the forward sweep
+        for (int base = 0; base < items; base += R * NT) {
+            if (base > 0) issue(base);
+            ex.wpar([&](int lane) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = base + r * NT + lane;
+                    if (e < items) {
+                        const int k = e / NX, j = e - k * NX, i6 = j < 6 ? j : j - 6;
+                        double vh = 0.0, ee = 0.0;
+                        if (k < Nl) {
+                            const double *gt = GT + (size_t)k * 18, *w = RW + (size_t)k * 12, *pn = rm.P + (size_t)(k + 1) * 12;
+                            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                            for (int m = 0; m < 6; m += 2) {
+                                const double h0 = gt[m] + P.b1[m] * (pn[m] + w[m]) + P.b2[m] * (pn[6 + m] + w[6 + m]);
+                                const double h1 = gt[m + 1] + P.b1[m + 1] * (pn[m + 1] + w[m + 1]) + P.b2[m + 1] * (pn[7 + m] + w[7 + m]);
+                                v0 += ld[r][m].at(lane) * h0; v1 += ld[r][m + 1].at(lane) * h1;
+                            }
+                            vh = v0 + v1;
+                            ee = ld[r][6].at(lane) - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
+                        }
+                        if (j < 6) rm.VH[(size_t)k * 6 + j] = vh;
+                        rm.E[(size_t)k * 12 + j] = ee;
+                    }
+                }
+            });
+        }
+        ex.barrier();
+        PROF_ADD(PF_BWD, t0);
+    }
+
     // =========================================================================== IPM driver
     // Restates HPIPM's d_ocp_qp_ipm_solve main loop (see oracle/mpc_oracle.c ipm_solve).
     // Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
@@ -1362,6 +1862,7 @@ struct Engine {
     {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
+        const bool res = resident_ok();   // the horizon's factor fits the LDS pool: resident sweeps
         residual_pass(0, 0.0);
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
@@ -1376,17 +1877,27 @@ struct Engine {
             else if (it >= c.pb->qp_iter_max) stop = 1;
             else if (!(alpha > 1e-12)) stop = 2;
             stop = ex.uni(stop);
+#ifdef MPCB_DIAG_FIXED_IT   // timing-only diagnostic builds: the same work whatever the (possibly knocked-out) arithmetic
+            stop = it >= MPCB_DIAG_FIXED_IT ? 0 : -1;
+#endif
             if (stop >= 0) { status = stop; break; }
-            fact_pass();
             const bool has_bounds = ex.uni(nc > 0);
-            const double a_aff = has_bounds ? forward_step_pass<true>() : forward_step_pass<false>();
+            double a_aff;
+            if (res) {
+                fact_pass_t<true>();
+                a_aff = has_bounds ? fwd_resident<true>() : fwd_resident<false>();
+            } else {
+                fact_pass_t<false>();
+                a_aff = has_bounds ? forward_step_pass<true>() : forward_step_pass<false>();
+            }
             if (has_bounds) {
-                const double S0 = ex.get1(sm.red[1]), S1 = ex.get1(sm.red[2]), S2 = ex.get1(sm.red[3]);
+                const double S0 = res ? ex.uni(sm.cen[1]) : ex.get1(sm.red[1]), S1 = res ? ex.uni(sm.cen[2]) : ex.get1(sm.red[2]),
+                             S2 = res ? ex.uni(sm.cen[3]) : ex.get1(sm.red[3]);
                 const double mu_aff = (S0 + a_aff * (S1 + a_aff * S2)) / nc;
                 const double tmp = mu_aff / mu;
                 const double sigma = tmp * tmp * tmp;
-                corrector_bwd_pass(sigma * mu);
-                alpha = forward_step_pass<false>();
+                if (res) { corr_resident(sigma * mu); alpha = fwd_resident<false>(); }
+                else { corrector_bwd_pass(sigma * mu); alpha = forward_step_pass<false>(); }
             } else {
                 alpha = a_aff;
             }

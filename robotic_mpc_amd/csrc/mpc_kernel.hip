@@ -79,6 +79,19 @@ struct DevExec {
         if (NWV == 1) wave_fence();
         else __syncthreads();
     }
+    // wave-local phase on EVERY wavefront, no workgroup barrier: consecutive wpar phases of one wavefront see each
+    // other's LDS writes (in-order LDS); data of another wavefront needs a barrier() first
+    template <class F>
+    __device__ __forceinline__ void wpar(F &&f)
+    {
+        f(lane_id());
+        wave_fence();
+    }
+    __device__ __forceinline__ static void barrier()
+    {
+        if (NWV == 1) wave_fence();
+        else __syncthreads();
+    }
     // phase on wavefront 0 only; consecutive seq phases need no s_barrier (one wave, in-order LDS)
     template <class F>
     __device__ __forceinline__ void seq(F &&f)
@@ -158,6 +171,9 @@ struct DevExec {
     // (DPP row shifts, rows of 16 lanes; used by lanes < 12 only).
     __device__ __forceinline__ static void share(double *, int, double) {}
     __device__ __forceinline__ static double gather(const double *, int j, double mine) { return row_lane(mine, j); }
+    // entry `idx` of a small LDS array whose 16-byte item l lane l of this wavefront has just read (`mine` = the half
+    // holding the entry, `src` = idx / 2): a scalar here; the host executor reads the array
+    __device__ __forceinline__ static double lane_value(const double *, int, double mine, int src) { return row_lane(mine, src); }
     __device__ __forceinline__ static double shl6(const double *, int, double mine) { return dpp<0x106>(mine); }
     __device__ __forceinline__ static double shr6(const double *, int, double mine) { return dpp<0x116>(mine); }
     // ---- reductions over the NT lanes of a simulation ------------------------------------

@@ -12,8 +12,8 @@
 #include <vector>
 #include <type_traits>
 
-#include "../../robotic-mpc_amd/csrc/mpc_core.h"
-#include "../../robotic-mpc_amd/csrc/mpc_pack.h"
+#include "../../robotic_mpc_amd/csrc/mpc_core.h"
+#include "../../robotic_mpc_amd/csrc/mpc_pack.h"
 
 using namespace mpcb;
 
@@ -39,6 +39,12 @@ struct HostExec {
     {
         for (int l = 0; l < NT; l++) f(l);
     }
+    template <class F>
+    void wpar(F &&f)     // wave-local phase on every wavefront: the wavefronts are independent, any order is valid
+    {
+        for (int l = 0; l < NT; l++) f(l);
+    }
+    static void barrier() {}
     template <class F>
     void seq(F &&f)
     {
@@ -69,6 +75,7 @@ struct HostExec {
     // lane-to-lane hand-over between seq phases: through the (double-buffered) slot array here
     static void share(double *slot, int lane, double v) { slot[lane] = v; }
     static double gather(const double *slot, int j, double) { return slot[j]; }
+    static double lane_value(const double *arr, int idx, double, int) { return arr[idx]; }
     static double shl6(const double *slot, int lane, double) { return lane + 6 < 12 ? slot[lane + 6] : 0.0; }
     static double shr6(const double *slot, int lane, double) { return lane >= 6 && lane < 12 ? slot[lane - 6] : 0.0; }
     // lanes run one after the other here: the slot accumulates in lane order
