@@ -710,6 +710,293 @@ struct Engine {
         PROF_ADD(PF_RES, t0);
     }
 
+    // =========================================================================== IPM: residual pass, item-parallel
+    // Same algebra as residual_pass (which it replaces), no LDS staging and no chunks: every lane works on ITEMS whose
+    // operands it loads straight from HBM (8- and 16-byte loads, coalesced in runs of 6..12 doubles), all loads of a
+    // batch of items in flight before the first is used.
+    //   U  elementwise update of (dw, pi, lam, t) -- every element is read and written by exactly one item;
+    //   Y  y_ki = w_i (r_ki + G_ki . delta_k)  -> LDS (and HBM: the SQP merit weights read stage 0's);
+    //   S  stationarity / bound items (u_j and v_j of a joint together; q_j), D  dynamics residual items:
+    //      read the updated iterate only, write the residual records (G2: Gamma | gt | rb, G3: rg | rd | rm).
+    // Workgroup barriers separate U | Y | S,D (vector-memory operations of one CU are performed in order by its L1).
+    MPC_PASS void residual_direct(int mode, double a)
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3;
+        double *const Y = ex.pool();   // [NS][6]: y of every stage (5 used)
+        typename Ex::template PerLane<double> n_g, n_b, n_d, n_m, n_mu, n_c;
+        PROF_T0(tx);
+        // ---------------------------------------------------------------- U: 16-byte items e2 < 39 of every stage
+        {
+            // (a CU's HBM rate is bytes in flight / latency, ~1.5 us here: all items of a lane in ONE batch, 2 x 16 loads of 16 B)
+            constexpr int R = 16, IPS = 39;   // items per stage: G1 columns [18, 96) = dw 18 | pi 12 | lam 24 | t 24
+            const int items = NS * IPS;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    D2 cur[R], stp[R];
+                    if (base == 0) { n_g.at(lane) = 0; n_b.at(lane) = 0; n_d.at(lane) = 0; n_m.at(lane) = 0; n_mu.at(lane) = 0; n_c.at(lane) = 0; }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                        cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * W1 + O_QW + c);
+                        if (mode == 1) {
+                            // the step sits in G3 [O_DW, ..) in the same order; dpi of the multiplier k -> k+1 is stored with stage k+1
+                            const int ks = (c >= 18 && c < 30) ? imin(k + 1, Nl) : k;
+                            stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)ks * W3 + O_DW + c);
+                        }
+                    }
+                    double ncl = n_c.at(lane);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / IPS, c = 2 * (e - k * IPS);
+                            D2 v = cur[r];
+                            if (c < 18) {
+                                if (mode == 1) { v.x += a * stp[r].x; v.y += a * stp[r].y; }
+                                else {
+                                    if (k == 0 && c >= 6) {            // embed x_0: delta x_0 = x_hat - x_0 (lbx_0 = ubx_0)
+                                        const double x0 = gld(G1 + O_X + c - 6), x1 = gld(G1 + O_X + c - 5);
+                                        v.x = sm.xhat[c - 6] - x0; v.y = sm.xhat[c - 5] - x1;
+                                    }
+                                    if (k == Nl && c < 6) { v.x = 0.0; v.y = 0.0; }
+                                }
+                            } else if (c < 30) {
+                                if (mode == 1 && k < Nl) { v.x += a * stp[r].x; v.y += a * stp[r].y; }
+                            } else {
+                                // lam (c in [30,54)) or t (c in [54,78)); side: lower 12 | upper 12; bounded component j
+                                const bool is_t = c >= 54;
+                                const int q = c - (is_t ? 54 : 30), j = q < 12 ? q : q - 12;
+                                const bool lo = q < 12;
+                                double xe[2] = {v.x, v.y};
+#pragma unroll
+                                for (int h = 0; h < 2; h++) {
+                                    const int jj = j + h;
+                                    const bool hc = has_comp(Nl, k, jj);
+                                    const bool on = hc && (lo ? bnd_lo(P, jj) > -BOUND_INF : bnd_hi(P, jj) < BOUND_INF);
+                                    const double d = h == 0 ? stp[r].x : stp[r].y;
+                                    if (mode == 0) {
+                                        xe[h] = on ? fmax(xe[h], 0.1) : (is_t ? 1.0 : 0.0);
+                                        if (on && !is_t) ncl += 1.0;
+                                    } else if (on) {
+                                        xe[h] = fmax(xe[h] + a * d, 1e-16);
+                                    }
+                                }
+                                v.x = xe[0]; v.y = xe[1];
+                            }
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QW + c) = v;
+                        }
+                    }
+                    n_c.at(lane) = ncl;
+                });
+            }
+        }
+        ex.barrier();
+        PROF_ADD(PF_X1, tx);
+        PROF_T0(ty);
+        // ---------------------------------------------------------------- Y: items (k < N, i < 5)
+        {
+            constexpr int R = 2;
+            const int items = Nl * NTASK;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    double g[R][12], d[R][12], rr[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / NTASK, i = e - k * NTASK;
+                        const double *g1 = G1 + (size_t)k * W1 + O_QW, *g2 = G2 + (size_t)k * W2;
+                        rr[r] = gld(g2 + O_R + i);
+#pragma unroll
+                        for (int j = 0; j < 6; j++) { g[r][j] = gld(g2 + O_GQ + i * 6 + j); d[r][j] = gld(g1 + 6 + j); }
+                        if (i == 4) {
+#pragma unroll
+                            for (int j = 0; j < 6; j++) { g[r][6 + j] = gld(g2 + O_GV + j); d[r][6 + j] = gld(g1 + 12 + j); }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / NTASK, i = e - k * NTASK;
+                            double v = rr[r];
+#pragma unroll
+                            for (int j = 0; j < 6; j++) v += g[r][j] * d[r][j];
+                            if (i == 4) {
+#pragma unroll
+                                for (int j = 0; j < 6; j++) v += g[r][6 + j] * d[r][6 + j];
+                            }
+                            v *= P.w_task[i];
+                            Y[k * 6 + i] = v;
+                            gst(G2 + (size_t)k * W2 + O_Y + i, v);
+                        }
+                    }
+                });
+            }
+        }
+        ex.barrier();
+        PROF_ADD(PF_X2, ty);
+        PROF_T0(tz);
+        // ---------------------------------------------------------------- S: joint items (k, j < 6), two kinds
+        {
+            constexpr int R = 3;
+            const int items = NS * 6;
+            const double dt = P.dt, lm = P.lm;
+            // bound part of a bounded component ci (value `val`, step `dv`): returns gt, updates rg, writes rd | rm | Gamma
+            auto bounds = [&](int lane, int k, int ci, double val_, double dv, double l_lo, double l_hi, double t_lo, double t_hi,
+                              double &rg) {
+                const bool hc = has_comp(Nl, k, ci);
+                const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                const double val = hc ? val_ : 0.0;
+                double gt = rg, gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
+                double a_d = n_d.at(lane), a_m = n_m.at(lane), a_mu = n_mu.at(lane);
+                if (blo) {
+                    const double l = l_lo, t = t_lo, it = fast_rcp(t);
+                    rdl = dv - (bnd_lo(P, ci) - val) - t;
+                    rml = l * t;
+                    rg -= l; gt -= l;
+                    gam += l * it;
+                    gt += (rml + l * rdl) * it;
+                    a_mu += rml;
+                    a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
+                }
+                if (bhi) {
+                    const double l = l_hi, t = t_hi, it = fast_rcp(t);
+                    rdu = (bnd_hi(P, ci) - val) - dv - t;
+                    rmu = l * t;
+                    rg += l; gt += l;
+                    gam += l * it;
+                    gt -= (rmu + l * rdu) * it;
+                    a_mu += rmu;
+                    a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
+                }
+                n_d.at(lane) = a_d; n_m.at(lane) = a_m; n_mu.at(lane) = a_mu;
+                double *g3 = G3 + (size_t)k * W3, *g2 = G2 + (size_t)k * W2;
+                gst(g3 + O_RD + ci, rdl); gst(g3 + O_RD + 12 + ci, rdu);
+                gst(g3 + O_RM + ci, rml); gst(g3 + O_RM + 12 + ci, rmu);
+                gst(g2 + O_GAM + ci, gam);
+                return gt;
+            };
+            // ---- one phase: the operands of the u/v items, the q items and the dynamics items of a batch all in flight first
+            constexpr int RD = 2 * R;                 // twice as many dynamics items (12 per stage) as joint items (6)
+            const int items_d = NS * NX;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    double v[R][12], q[R][13], d[RD][5];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / 6, j = e - k * 6, km = imax(k - 1, 0);
+                        const double *g1 = G1 + (size_t)k * W1, *g2 = G2 + (size_t)k * W2, *gm = G1 + (size_t)km * W1;
+                        v[r][0] = gld(g1 + O_U + j);      v[r][1] = gld(g1 + O_X + 6 + j);
+                        v[r][2] = gld(g1 + O_QW + j);     v[r][3] = gld(g1 + O_QW + 12 + j);
+                        v[r][4] = gld(g1 + O_QPI + j);    v[r][5] = gld(g1 + O_QPI + 6 + j);
+                        v[r][6] = gld(gm + O_QPI + 6 + j);
+                        v[r][7] = gld(g2 + O_GV + j);
+                        v[r][8] = gld(g1 + O_QLAM + j);   v[r][9] = gld(g1 + O_QLAM + 12 + j);
+                        v[r][10] = gld(g1 + O_QT + j);    v[r][11] = gld(g1 + O_QT + 12 + j);
+                        q[r][0] = gld(g1 + O_X + j);  q[r][1] = gld(g1 + O_QW + 6 + j);
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) q[r][2 + i] = gld(g2 + O_GQ + i * 6 + j);
+                        q[r][7] = v[r][4]; q[r][8] = gld(gm + O_QPI + j);
+                        q[r][9] = gld(g1 + O_QLAM + 6 + j);  q[r][10] = gld(g1 + O_QLAM + 18 + j);
+                        q[r][11] = gld(g1 + O_QT + 6 + j);   q[r][12] = gld(g1 + O_QT + 18 + j);
+                    }
+#pragma unroll
+                    for (int r = 0; r < RD; r++) {
+                        const int e = imin(2 * base + r * NT + lane, items_d - 1), k = e / NX, i = e - k * NX, kn = imin(k + 1, Nl);
+                        const double *dw = G1 + (size_t)k * W1 + O_QW;
+                        d[r][0] = gld(dw + 6 + i);
+                        d[r][1] = gld(dw + (i < 6 ? 12 + i : i - 6));
+                        d[r][2] = gld(dw + (i < 6 ? i : i - 6));
+                        d[r][3] = gld(G2 + (size_t)k * W2 + O_BD + i);
+                        d[r][4] = gld(G1 + (size_t)kn * W1 + O_QW + 6 + i);
+                    }
+                    // u_j and v_j of joint j (they share u_j + du_j and v_j + dv_j)
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / 6, j = e - k * 6;
+                            const double du = v[r][2], dvv = v[r][3];
+                            const double uj = v[r][0] + du, vj = v[r][1] + dvv;
+                            const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+                            double *g3 = G3 + (size_t)k * W3, *g2 = G2 + (size_t)k * W2;
+                            // u_j (stat_cls<0>)
+                            double rgu = 0.0;
+                            if (k < Nl) {
+                                rgu = dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
+                                rgu += P.b1[j] * v[r][4] + P.b2[j] * v[r][5];
+                                rgu += dt * lm * du;
+                            }
+                            const double gtu = bounds(lane, k, j, v[r][0], du, v[r][8], v[r][9], v[r][10], v[r][11], rgu);
+                            gst(g3 + O_RG + j, rgu); gst(g2 + O_GT + j, gtu);
+                            // v_j (stat_cls<2>): no bounds
+                            double rgv = 0.0;
+                            if (k >= 1) {
+                                if (k < Nl) {
+                                    rgv = dt * (v[r][7] * Y[k * 6 + 4] + c2 * (vj - uj));
+                                    rgv += P.a12[j] * v[r][4] + P.a22[j] * v[r][5];
+                                }
+                                rgv += (k < Nl ? dt : 1.0) * lm * dvv;
+                                rgv -= v[r][6];
+                            }
+                            gst(g3 + O_RG + 12 + j, rgv); gst(g2 + O_GT + 12 + j, rgv);
+                            // q_j (stat_cls<1>); pi_k[j] is v[r][4]
+                            const double dq = q[r][1];
+                            double rg = 0.0;
+                            if (k >= 1) {
+                                if (k < Nl) {
+                                    double s_ = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < NTASK; i++) s_ += q[r][2 + i] * Y[k * 6 + i];
+                                    rg = dt * s_ + q[r][7];
+                                }
+                                rg += (k < Nl ? dt : 1.0) * lm * dq;
+                                rg -= q[r][8];
+                            }
+                            const double gt = bounds(lane, k, 6 + j, q[r][0], dq, q[r][9], q[r][10], q[r][11], q[r][12], rg);
+                            gst(g3 + O_RG + 6 + j, rg); gst(g2 + O_GT + 6 + j, gt);
+                            n_g.at(lane) = fmax(n_g.at(lane), fmax(fmax(fabs(rgu), fabs(rgv)), fabs(rg)));
+                        }
+                    }
+                    // dynamics residual of (k, i)
+#pragma unroll
+                    for (int r = 0; r < RD; r++) {
+                        const int e = 2 * base + r * NT + lane;
+                        if (e < items_d && e < 2 * (base + R * NT)) {
+                            const int k = e / NX, i = e - k * NX;
+                            double vv = 0.0;
+                            if (k < Nl) {
+                                if (i < 6) vv = d[r][0] + P.a12[i] * d[r][1] + P.b1[i] * d[r][2];
+                                else vv = P.a22[i - 6] * d[r][0] + P.b2[i - 6] * d[r][1];
+                                vv += d[r][3] - d[r][4];
+                                n_b.at(lane) = fmax(n_b.at(lane), fabs(vv));
+                            }
+                            gst(G2 + (size_t)k * W2 + O_RB + i, vv);
+                        }
+                    }
+                });
+            }
+        }
+        PROF_ADD(PF_X3, tz);
+        ex.par([&](int lane) {
+            ex.put_max(sm.red[0], lane, n_g.at(lane)); ex.put_max(sm.red[1], lane, n_b.at(lane));
+            ex.put_max(sm.red[2], lane, n_d.at(lane)); ex.put_max(sm.red[3], lane, n_m.at(lane));
+            ex.put_sum(sm.red[4], lane, n_mu.at(lane)); ex.put_sum(sm.red[5], lane, n_c.at(lane));
+        });
+        const double ng = ex.get_max(sm.red[0]), nb = ex.get_max(sm.red[1]), nd = ex.get_max(sm.red[2]), nm = ex.get_max(sm.red[3]);
+        const double smu = ex.get_sum(sm.red[4]), nc = ex.get_sum(sm.red[5]);
+        ex.par([&](int lane) {
+            if ((lane & (WAVE - 1)) == 0) {
+                sm.ret[0] = ng; sm.ret[1] = nb; sm.ret[2] = nd; sm.ret[3] = nm; sm.ret[4] = smu;
+                if (mode == 0) sm.ret[5] = nc;
+            }
+        });
+        PROF_ADD(PF_RES, t0);
+    }
+
     // =========================================================================== Riccati passes
     // Factorisation sweep.  Lane l < 36 owns block position (a,b) = (l/6, l%6) of the 12x12
     // cost-to-go M = [[Mqq Mqv],[Mvq Mvv]] -- its four entries live in the lane's registers for
@@ -1863,7 +2150,11 @@ struct Engine {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
         const bool res = resident_ok();   // the horizon's factor fits the LDS pool: resident sweeps
+#ifdef MPCB_OLD_RESIDUAL
         residual_pass(0, 0.0);
+#else
+        residual_direct(0, 0.0);
+#endif
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         int it = 0, status = 1;
@@ -1902,7 +2193,11 @@ struct Engine {
                 alpha = a_aff;
             }
             const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
+#ifdef MPCB_OLD_RESIDUAL
             residual_pass(1, a);
+#else
+            residual_direct(1, a);
+#endif
             mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         }
 #ifdef MPCB_PROFILE
