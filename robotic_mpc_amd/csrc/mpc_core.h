@@ -134,6 +134,12 @@ MPC_HD void load_constants(Ex &ex, const InstParams *P, const Robot *rb)
         const double *rs = reinterpret_cast<const double *>(rb);
         double *rd = reinterpret_cast<double *>(&sm.rb);
         for (int e = lane; e < (int)(sizeof(Robot) / sizeof(double)); e += Ex::NT) rd[e] = rs[e];
+        if (lane < 24) {   // which bound sides exist (|bound| >= 1e29 means absent, include/mpcbatch.h)
+            const int j = lane < 12 ? lane : lane - 12;
+            const double b = lane < 12 ? (j < 6 ? ps[offsetof(InstParams, umin) / 8 + j] : ps[offsetof(InstParams, qmin) / 8 + j - 6])
+                                       : (j < 6 ? ps[offsetof(InstParams, umax) / 8 + j] : ps[offsetof(InstParams, qmax) / 8 + j - 6]);
+            sm.bon[lane] = (lane < 12 ? b > -BOUND_INF : b < BOUND_INF) ? 1.0 : 0.0;
+        }
     });
 }
 
@@ -729,65 +735,77 @@ struct Engine {
         double *const Y = ex.pool();   // [NS][6]: y of every stage (5 used)
         typename Ex::template PerLane<double> n_g, n_b, n_d, n_m, n_mu, n_c;
         PROF_T0(tx);
-        // ---------------------------------------------------------------- U: 16-byte items e2 < 39 of every stage
-        {
-            // (a CU's HBM rate is bytes in flight / latency, ~1.5 us here: all items of a lane in ONE batch, 2 x 16 loads of 16 B)
-            constexpr int R = 16, IPS = 39;   // items per stage: G1 columns [18, 96) = dw 18 | pi 12 | lam 24 | t 24
+        // ---------------------------------------------------------------- U: 16-byte items (pairs never straddle a field)
+        // (a CU's HBM rate is bytes in flight / latency, ~1.5 us here: all items of a lane in ONE batch; and everything in
+        // this kernel is bound by one wavefront's instruction issue, ~6 cycles each: the items are as lean as they can be)
+        ex.wpar([&](int lane) { n_g.at(lane) = 0; n_b.at(lane) = 0; n_d.at(lane) = 0; n_m.at(lane) = 0; n_mu.at(lane) = 0; n_c.at(lane) = 0; });
+        if (mode == 1) {
+            // dw (18) | pi (12) += a * step: G1 columns [18, 48) <- G3 columns [66, 96); dpi of multiplier k -> k+1 sits with stage k+1
+            constexpr int R = 6, IPS = 15;
             const int items = NS * IPS;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
                     D2 cur[R], stp[R];
-                    if (base == 0) { n_g.at(lane) = 0; n_b.at(lane) = 0; n_d.at(lane) = 0; n_m.at(lane) = 0; n_mu.at(lane) = 0; n_c.at(lane) = 0; }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
                         cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * W1 + O_QW + c);
-                        if (mode == 1) {
-                            // the step sits in G3 [O_DW, ..) in the same order; dpi of the multiplier k -> k+1 is stored with stage k+1
-                            const int ks = (c >= 18 && c < 30) ? imin(k + 1, Nl) : k;
-                            stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)ks * W3 + O_DW + c);
+                        stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)(c >= 18 ? imin(k + 1, Nl) : k) * W3 + O_DW + c);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / IPS, c = 2 * (e - k * IPS);
+                            const double aa = (c >= 18 && k >= Nl) ? 0.0 : a;   // no multiplier beyond the last dynamics
+                            D2 v = cur[r];
+                            v.x += aa * stp[r].x; v.y += aa * stp[r].y;
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QW + c) = v;
                         }
+                    }
+                });
+            }
+        } else {
+            // HPIPM warm start: the previous (w, pi) stay; embed x_0 (lbx_0 = ubx_0 = x_hat); no input at stage N
+            ex.wpar([&](int lane) {
+                if (lane < NX) gst(G1 + O_QW + 6 + lane, sm.xhat[lane] - gld(G1 + O_X + lane));
+                if (lane >= 16 && lane < 16 + NU) gst(G1 + (size_t)Nl * W1 + O_QW + lane - 16, 0.0);
+            });
+        }
+        {
+            // lam (24) | t (24): G1 columns [48, 96) <- G3 columns [96, 144); q = column - 48: lam lower 12 | upper 12 | t lower | upper
+            constexpr int R = 10, IPS = 24;
+            const int items = NS * IPS;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    D2 cur[R], stp[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
+                        cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * W1 + O_QLAM + q);
+                        if (mode == 1) stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)k * W3 + O_DLAM + q);
                     }
                     double ncl = n_c.at(lane);
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int e = base + r * NT + lane;
                         if (e < items) {
-                            const int k = e / IPS, c = 2 * (e - k * IPS);
+                            const int k = e / IPS, q = 2 * (e - k * IPS);
+                            const bool is_t = q >= 24;
+                            const int sc = is_t ? q - 24 : q, j = sc < 12 ? sc : sc - 12;        // side/component, component
+                            const bool ok = j < 6 ? k < Nl : (k >= 1 && k < Nl);                 // has_comp (same for j and j + 1)
+                            const D2 m = *reinterpret_cast<const D2 *>(&sm.bon[sc]);
+                            const bool on0 = ok && m.x != 0.0, on1 = ok && m.y != 0.0;
                             D2 v = cur[r];
-                            if (c < 18) {
-                                if (mode == 1) { v.x += a * stp[r].x; v.y += a * stp[r].y; }
-                                else {
-                                    if (k == 0 && c >= 6) {            // embed x_0: delta x_0 = x_hat - x_0 (lbx_0 = ubx_0)
-                                        const double x0 = gld(G1 + O_X + c - 6), x1 = gld(G1 + O_X + c - 5);
-                                        v.x = sm.xhat[c - 6] - x0; v.y = sm.xhat[c - 5] - x1;
-                                    }
-                                    if (k == Nl && c < 6) { v.x = 0.0; v.y = 0.0; }
-                                }
-                            } else if (c < 30) {
-                                if (mode == 1 && k < Nl) { v.x += a * stp[r].x; v.y += a * stp[r].y; }
+                            if (mode == 1) {
+                                const double n0 = fmax(v.x + a * stp[r].x, 1e-16), n1 = fmax(v.y + a * stp[r].y, 1e-16);
+                                v.x = on0 ? n0 : v.x; v.y = on1 ? n1 : v.y;
                             } else {
-                                // lam (c in [30,54)) or t (c in [54,78)); side: lower 12 | upper 12; bounded component j
-                                const bool is_t = c >= 54;
-                                const int q = c - (is_t ? 54 : 30), j = q < 12 ? q : q - 12;
-                                const bool lo = q < 12;
-                                double xe[2] = {v.x, v.y};
-#pragma unroll
-                                for (int h = 0; h < 2; h++) {
-                                    const int jj = j + h;
-                                    const bool hc = has_comp(Nl, k, jj);
-                                    const bool on = hc && (lo ? bnd_lo(P, jj) > -BOUND_INF : bnd_hi(P, jj) < BOUND_INF);
-                                    const double d = h == 0 ? stp[r].x : stp[r].y;
-                                    if (mode == 0) {
-                                        xe[h] = on ? fmax(xe[h], 0.1) : (is_t ? 1.0 : 0.0);
-                                        if (on && !is_t) ncl += 1.0;
-                                    } else if (on) {
-                                        xe[h] = fmax(xe[h] + a * d, 1e-16);
-                                    }
-                                }
-                                v.x = xe[0]; v.y = xe[1];
+                                const double off = is_t ? 1.0 : 0.0;
+                                v.x = on0 ? fmax(v.x, 0.1) : off; v.y = on1 ? fmax(v.y, 0.1) : off;
+                                ncl += (on0 && !is_t ? 1.0 : 0.0) + (on1 && !is_t ? 1.0 : 0.0);
                             }
-                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QW + c) = v;
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QLAM + q) = v;
                         }
                     }
                     n_c.at(lane) = ncl;
@@ -847,32 +865,25 @@ struct Engine {
             // bound part of a bounded component ci (value `val`, step `dv`): returns gt, updates rg, writes rd | rm | Gamma
             auto bounds = [&](int lane, int k, int ci, double val_, double dv, double l_lo, double l_hi, double t_lo, double t_hi,
                               double &rg) {
-                const bool hc = has_comp(Nl, k, ci);
-                const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
+                // branch-free: an absent bound side holds lam = 0, t = 1, so its terms vanish by themselves; only rd needs a select
+                const bool hc = ci < 6 ? k < Nl : (k >= 1 && k < Nl);
+                const bool blo = hc && sm.bon[ci] != 0.0, bhi = hc && sm.bon[12 + ci] != 0.0;
                 const double val = hc ? val_ : 0.0;
-                double gt = rg, gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
-                double a_d = n_d.at(lane), a_m = n_m.at(lane), a_mu = n_mu.at(lane);
-                if (blo) {
-                    const double l = l_lo, t = t_lo, it = fast_rcp(t);
-                    rdl = dv - (bnd_lo(P, ci) - val) - t;
-                    rml = l * t;
-                    rg -= l; gt -= l;
-                    gam += l * it;
-                    gt += (rml + l * rdl) * it;
-                    a_mu += rml;
-                    a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
-                }
-                if (bhi) {
-                    const double l = l_hi, t = t_hi, it = fast_rcp(t);
-                    rdu = (bnd_hi(P, ci) - val) - dv - t;
-                    rmu = l * t;
-                    rg += l; gt += l;
-                    gam += l * it;
-                    gt -= (rmu + l * rdu) * it;
-                    a_mu += rmu;
-                    a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
-                }
-                n_d.at(lane) = a_d; n_m.at(lane) = a_m; n_mu.at(lane) = a_mu;
+                const double ll = blo ? l_lo : 0.0, lu = bhi ? l_hi : 0.0;
+                const double itl = fast_rcp(t_lo), itu = fast_rcp(t_hi);
+                const double rdl = blo ? dv - (bnd_lo(P, ci) - val) - t_lo : 0.0;
+                const double rdu = bhi ? (bnd_hi(P, ci) - val) - dv - t_hi : 0.0;
+                const double rml = ll * t_lo, rmu = lu * t_hi;
+                double gt = rg;
+                rg -= ll; gt -= ll;
+                double gam = ll * itl;
+                gt += (rml + ll * rdl) * itl;
+                rg += lu; gt += lu;
+                gam += lu * itu;
+                gt -= (rmu + lu * rdu) * itu;
+                n_mu.at(lane) += rml + rmu;
+                n_d.at(lane) = fmax(n_d.at(lane), fmax(fabs(rdl), fabs(rdu)));
+                n_m.at(lane) = fmax(n_m.at(lane), fmax(fabs(rml), fabs(rmu)));
                 double *g3 = G3 + (size_t)k * W3, *g2 = G2 + (size_t)k * W2;
                 gst(g3 + O_RD + ci, rdl); gst(g3 + O_RD + 12 + ci, rdu);
                 gst(g3 + O_RM + ci, rml); gst(g3 + O_RM + 12 + ci, rmu);
@@ -1808,7 +1819,15 @@ struct Engine {
                 z.at(lane) = vec[(size_t)k * 12 + i] + (at - (acc0 + acc1));
             }
         };
-        // local sweeps of all chunks; STORE: pass 3 (writes the results), else pass 1 (zero boundary value)
+        // local sweeps of all chunks; STORE: pass 3 (writes the results), else pass 1 (zero boundary value).
+        // Per-lane chunk geometry (first / one-past-last transition, activity) is worked out once, not per step.
+        typename Ex::template PerLane<int> g_ks, g_n;    // first transition of the lane's chunk, number of steps (0: lane idle)
+        ex.wpar([&](int lane) {
+            const int c = lane >> 4, i = lane & 15;
+            const int ks = c * L, ke = imin(ks + L, Nl);
+            g_ks.at(lane) = ks;
+            g_n.at(lane) = (lane < RS_GROUPS * 16 && i < NX && ke > ks) ? ke - ks : 0;
+        });
         auto sweep = [&](auto store_tag) {
             constexpr bool STORE = decltype(store_tag)::value;
             ex.wpar([&](int lane) {
@@ -1822,21 +1841,18 @@ struct Engine {
             });
             for (int t = 0; t < L; t++) {
                 ex.wpar([&](int lane) {
-                    const int c = lane >> 4, i = lane & 15;
-                    const int ks = c * L, ke = imin(ks + L, Nl);
-                    const int k = FWD ? ks + t : ke - 1 - t;
-                    if (lane < RS_GROUPS * 16 && i < NX && k >= ks && k < ke) step_compute(lane, k);
+                    const int n = g_n.at(lane), ks = g_ks.at(lane);
+                    if (t < n) step_compute(lane, FWD ? ks + t : ks + n - 1 - t);
                 });
                 ex.wpar([&](int lane) {
-                    const int c = lane >> 4, i = lane & 15;
-                    const int ks = c * L, ke = imin(ks + L, Nl);
-                    const int k = FWD ? ks + t : ke - 1 - t;
-                    if (lane < RS_GROUPS * 16 && i < NX && k >= ks && k < ke) {
+                    const int n = g_n.at(lane), ks = g_ks.at(lane);
+                    if (t < n) {
+                        const int c = lane >> 4, i = lane & 15, k = FWD ? ks + t : ks + n - 1 - t;
                         const double v = z.at(lane);
                         xch[c * 12 + i] = v;
                         if (STORE) {
                             // FWD: v = dx_{k+1}; the first stage of the next chunk belongs to that chunk (boundary value)
-                            if (FWD) { if (k + 1 < ke || k + 1 == Nl) vec[(size_t)(k + 1) * 12 + i] = v; }
+                            if (FWD) { if (t + 1 < n || k + 1 == Nl) vec[(size_t)(k + 1) * 12 + i] = v; }
                             else vec[(size_t)k * 12 + i] = v;
                         }
                     }
@@ -1899,22 +1915,27 @@ struct Engine {
         const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
         const ResMap rm = res_map();
         double *X = rm.scr, *xch = X + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
-        const int items = NS * NB;
-        constexpr int R = RS_ROUNDS;
+        const int items = NS * 6;      // joint items (k, j): the bounded components u_j and q_j together
+        const int items_pi = NS * NB;  // dpi items (k, state component)
+        constexpr int R = 3;
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
-        typename Ex::template PerLane<double> ld[R][8];
+        typename Ex::template PerLane<double> ld[R][16];
         typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
-        // operands of a batch of items: lam, t (G1), rd, rm (G3), lower | upper -- unconditional, clamped
+        // operands of a batch of items: lam, t (G1), rd, rm (G3); lower | upper of u_j, then of q_j -- unconditional, clamped
         auto issue = [&](int base) {
             ex.wpar([&](int lane) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
+                    const int e = imin(base + r * NT + lane, items - 1), k = e / 6, j = e - k * 6;
                     const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
-                    ld[r][0].at(lane) = gld(g1 + O_QLAM + j); ld[r][1].at(lane) = gld(g1 + O_QLAM + 12 + j);
-                    ld[r][2].at(lane) = gld(g1 + O_QT + j);   ld[r][3].at(lane) = gld(g1 + O_QT + 12 + j);
-                    ld[r][4].at(lane) = gld(g3 + O_RD + j);   ld[r][5].at(lane) = gld(g3 + O_RD + 12 + j);
-                    ld[r][6].at(lane) = gld(g3 + O_RM + j);   ld[r][7].at(lane) = gld(g3 + O_RM + 12 + j);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int c = j + 6 * h;
+                        ld[r][8 * h + 0].at(lane) = gld(g1 + O_QLAM + c); ld[r][8 * h + 1].at(lane) = gld(g1 + O_QLAM + 12 + c);
+                        ld[r][8 * h + 2].at(lane) = gld(g1 + O_QT + c);   ld[r][8 * h + 3].at(lane) = gld(g1 + O_QT + 12 + c);
+                        ld[r][8 * h + 4].at(lane) = gld(g3 + O_RD + c);   ld[r][8 * h + 5].at(lane) = gld(g3 + O_RD + 12 + c);
+                        ld[r][8 * h + 6].at(lane) = gld(g3 + O_RM + c);   ld[r][8 * h + 7].at(lane) = gld(g3 + O_RM + 12 + c);
+                    }
                 }
                 if (base == 0) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; }
             });
@@ -1928,54 +1949,58 @@ struct Engine {
             if (base > 0) issue(base);
             ex.wpar([&](int lane) {
                 double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
+                // one bound side (HPIPM compute_lam_t + the step-length and centering contributions), branch-free: an absent
+                // side holds lam = 0, t = 1, rd = rm = 0 and `on` zeroes its dt, so its dlam and all its sums vanish
+                auto side = [&](bool on, double sdv, double l, double t, double rd, double rmv, double &dt_o, double &dl_o) {
+                    const double dt = on ? sdv + rd : 0.0;
+                    const double dl = on ? -(rmv + l * dt) * fast_rcp(t) : 0.0;
+                    const double c1 = -l * fast_rcp(dl);
+                    al = (dl < 0 && l + al * dl < 0) ? c1 : al;
+                    const double c2 = -t * fast_rcp(dt);
+                    al = (dt < 0 && t + al * dt < 0) ? c2 : al;
+                    a0 += l * t; a1 += l * dt + t * dl; a2 += dl * dt;
+                    dt_o = dt; dl_o = dl;
+                };
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int e = base + r * NT + lane;
                     if (e < items) {
-                        const int k = e / NB, j = e - k * NB;
+                        const int k = e / 6, j = e - k * 6;
                         const double *dxk = X + (size_t)k * 12;
                         double *g3 = G3 + (size_t)k * W3;
-                        double dv;
-                        if (j < 6) {
-                            dv = 0.0;
-                            if (k < Nl) {
-                                const double *kr = rm.K + (size_t)k * 72 + j * 12;
-                                double s0 = rm.VH[(size_t)k * 6 + j], s1 = 0.0;
+                        // du_k[j] = -(R~^-1 h_u + K dx_k)[j]  (stage N has no input: 0)
+                        const int kc = imin(k, Nl - 1);
+                        const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)kc * 72 + j * 12);
+                        const D2 *x2 = reinterpret_cast<const D2 *>(dxk);
+                        double s0 = rm.VH[(size_t)kc * 6 + j], s1 = 0.0;
 #pragma unroll
-                                for (int i = 0; i < NX; i += 2) { s0 += kr[i] * dxk[i]; s1 += kr[i + 1] * dxk[i + 1]; }
-                                dv = -(s0 + s1);
-                            }
-                            if (!AFFINE) gst(g3 + O_DW + j, dv);          // du_k (stage N has no input: 0)
-                        } else {
-                            dv = dxk[j - 6];
+                        for (int i = 0; i < NX; i += 2) { const D2 kv = kr[i >> 1], xv = x2[i >> 1]; s0 += kv.x * xv.x; s1 += kv.y * xv.y; }
+                        const double du = k < Nl ? -(s0 + s1) : 0.0, dq = dxk[j];
+                        if (!AFFINE) {
+                            gst(g3 + O_DW + j, du); gst(g3 + O_DW + 6 + j, dq); gst(g3 + O_DW + 12 + j, dxk[6 + j]);   // du_k, dx_k
                         }
-                        if (!AFFINE) gst(g3 + O_DW + 6 + j, dxk[j]);      // dx_k, all twelve components
-                        const bool hc = has_comp(Nl, k, j);
-                        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
-                        const double ll = ld[r][0].at(lane), lu = ld[r][1].at(lane), tl = ld[r][2].at(lane), tu = ld[r][3].at(lane);
-                        const double rdl = ld[r][4].at(lane), rdu = ld[r][5].at(lane), rml = ld[r][6].at(lane), rmu = ld[r][7].at(lane);
-                        double dtl = 0, dll = 0, dtu = 0, dlu = 0;
-                        if (blo) {
-                            dtl = dv + rdl;
-                            dll = -(rml + ll * dtl) * fast_rcp(tl);
-                            if (dll < 0 && ll + al * dll < 0) al = -ll * fast_rcp(dll);
-                            if (dtl < 0 && tl + al * dtl < 0) al = -tl * fast_rcp(dtl);
-                            a0 += ll * tl; a1 += ll * dtl + tl * dll; a2 += dll * dtl;
+                        const bool oku = k < Nl, okq = k >= 1 && k < Nl;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int c = j + 6 * h;
+                            const bool ok = h == 0 ? oku : okq;
+                            const bool blo = ok && sm.bon[c] != 0.0, bhi = ok && sm.bon[12 + c] != 0.0;
+                            const double dv = h == 0 ? du : dq;
+                            double dtl, dll, dtu, dlu;
+                            side(blo, dv, ld[r][8 * h + 0].at(lane), ld[r][8 * h + 2].at(lane), ld[r][8 * h + 4].at(lane), ld[r][8 * h + 6].at(lane), dtl, dll);
+                            side(bhi, -dv, ld[r][8 * h + 1].at(lane), ld[r][8 * h + 3].at(lane), ld[r][8 * h + 5].at(lane), ld[r][8 * h + 7].at(lane), dtu, dlu);
+                            gst(g3 + O_DLAM + c, dll); gst(g3 + O_DLAM + 12 + c, dlu);
+                            gst(g3 + O_DT + c, dtl);   gst(g3 + O_DT + 12 + c, dtu);
                         }
-                        if (bhi) {
-                            dtu = -dv + rdu;
-                            dlu = -(rmu + lu * dtu) * fast_rcp(tu);
-                            if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
-                            if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
-                            a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
-                        }
-                        gst(g3 + O_DLAM + j, dll); gst(g3 + O_DLAM + 12 + j, dlu);
-                        gst(g3 + O_DT + j, dtl);   gst(g3 + O_DT + 12 + j, dtu);
                     }
                 }
                 r_al.at(lane) = al; r_a0.at(lane) = a0; r_a1.at(lane) = a1; r_a2.at(lane) = a2;
             });
-            if (!AFFINE) {
+        }
+        if (!AFFINE) {
+            constexpr int R = RS_ROUNDS;
+            const int items = items_pi;
+            for (int base = 0; base < items; base += R * NT) {
                 // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1}): row j of the packed P_k from HBM
                 ex.wpar([&](int lane) {
                     double pm[R][12];
@@ -2053,8 +2078,8 @@ struct Engine {
                     const int e = base + r * NT + lane;
                     if (e < items) {
                         const int k = e / NB, j = e - k * NB;
-                        const bool hc = has_comp(Nl, k, j);
-                        const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                        const bool hc = j < 6 ? k < Nl : (k >= 1 && k < Nl);
+                        const bool blo = hc && sm.bon[j] != 0.0, bhi = hc && sm.bon[12 + j] != 0.0;
                         const double ll = v[r][0], lu = v[r][1], tl = v[r][2], tu = v[r][3];
                         const double dll = v[r][4], dlu = v[r][5], dtl = v[r][6], dtu = v[r][7], rdl = v[r][8], rdu = v[r][9];
                         double gt = v[r][10];

@@ -179,6 +179,7 @@ struct Smem {
     alignas(16) double dx[2][12];
     alignas(16) double ret[8];      // results a pass hands back to the solver driver (every wavefront writes the same values)
     alignas(16) double cen[4];      // resident sweeps: step length and the three centering sums S0, S1, S2
+    alignas(16) double bon[24];     // 1.0 where a bound exists: lower 12 (u 6 | q 6), upper 12 (stage rules: has_comp)
     alignas(16) double red[8][NWV_MAX];   // one partial per wavefront (Ex::put_* / get_*)
     alignas(16) double xhat[12];    // current plant state (feedback, simulator.py:206)
     alignas(16) double u0[6];
