@@ -61,8 +61,8 @@ extern "C" {
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
  * within 30 s is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
 #define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on, for runs of >= 100 closed-loop steps */
-#define MPCB_STREAM_MIN_BATCH 1280   /* measured crossover at N=100 on one MI355X: 1024 simulations 538 k (latency) vs 444 k,
-                                        1280: 510 k vs 546 k steps/s */
+#define MPCB_STREAM_MIN_BATCH 1408   /* measured crossover at N=100, 600 steps, one MI355X (profiles/r03_engine_sweep.txt): 1280 simulations
+                                        741 k (latency engine, two per CU) vs 720 k, 1536: ~745 k vs 826 k steps/s */
 
 typedef struct mpcb_handle mpcb_handle;
 

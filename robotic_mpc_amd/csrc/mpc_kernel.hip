@@ -574,6 +574,9 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         // beyond that the grid simply queues.  MPCB_SIMS_PER_CU overrides the residency target.
         int wpc = (p->batch + h->num_cus - 1) / h->num_cus;
         if (wpc > 2) wpc = 2;
+        // (Measured, N = 100, 600 steps, profiles/r03_engine_sweep.txt: batch 512 as two simulations per CU at half the pool on the
+        // streaming path 730 k steps/s; as one per CU with the LDS-resident factor, the grid running in two rounds, 640 k: two
+        // factorisation chains side by side on a CU beat one faster one, so the residency target stays 2 beyond #CUs.)
         if (const char *e2 = getenv("MPCB_SIMS_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 8) wpc = v; }
         const int lds_total = 160 * 1024, fixed = (int)sizeof(Smem) + 64;
         int bytes = lds_total / (wpc < 1 ? 1 : wpc) - fixed;
