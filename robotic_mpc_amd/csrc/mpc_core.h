@@ -1122,6 +1122,7 @@ struct Engine {
                             ab.at(lane) = c2;
                         }
                         if (lane < NU) vhp[lane] = 0.0;
+                        if (lane == 0) ex.post(&sm.prog1, 0);
                     });
                     continue;
                 }
@@ -1167,20 +1168,29 @@ struct Engine {
                         if (j < 6) vhp[j] = vh;
                         ep[j] = rbv[j] - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
                     }
+                    if (lane == 0) ex.post(&sm.prog1, Nl - k);
                 });
                 vcur = vnxt;
             }
         };
-        ex.par([&](int lane) { if (lane == 0) ex.post(&sm.prog, -1); });
+        // The windows are a PIPELINE without workgroup barriers (Ex::pipeline3): each role loops over the windows itself and
+        // the hand-overs are LDS counters -- the recursion wavefront never waits for its followers to catch up at a window end
+        // (that lag, ~1.3 us per window, was what a window cost):
+        //   sm.prog / sm.prog1   stages finished by the matrix / the vector recursion (Nl - k)
+        //   sm.flg[0]            input chunks landed in LDS, counted per background wavefront
+        //   sm.flg[1]            factor buffers released (stored, and no longer read by the vector recursion), per background wavefront
+        constexpr int NBW = Ex::BG_WAVES;
+        ex.par([&](int lane) {
+            if (lane == 0) { ex.post(&sm.prog, -1); ex.post(&sm.prog1, -1); ex.post(&sm.flg[0], NBW); ex.post(&sm.flg[1], 0); }
+        });
         load_rect<WR, O_GQ, W2>(vr_of(0), ex.smem().w.G2, imax(imax(Nl - CH + 1, 0) - 1, 0), Nl);
-        int ci = 0;
-        for (int k1 = Nl; k1 >= 0; k1 -= CH, ci++) {
-            const int k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
+        const int nwin = (Nl + CH) / CH;
+        PROF_T0(ts);
+        ex.pipeline3(nwin, [&](int ci) {
+            const int k1 = k1_of(ci), k0 = imax(k1 - CH + 1, 0), kl = imax(k0 - 1, 0);
             double *vr = vr_of(ci), *vf = vf_of(ci);
-            const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);   // chunk ci+1
-            const int pk1 = k1 + CH, pk0 = k1 + 1;                                          // chunk ci-1
-            PROF_T0(ts);
-            ex.overlap3([&]() {
+            ex.await(&sm.flg[0], NBW * (ci + 1));          // this chunk's inputs have landed
+            if (ci >= 2) ex.await(&sm.flg[1], NBW * ci);   // the factor buffer (that of chunk ci-2) is free
             for (int k = k1; k >= k0; k--) {
                 const double *ric = vr + (size_t)(k - kl) * WR;
                 const double *ricd = ric - WR;           // stage k-1 (valid for k >= 1)
@@ -1300,14 +1310,24 @@ struct Engine {
                 });
                 sb ^= 1;
             }
-            }, [&]() {
+            }, [&](int ci) {
 #ifndef MPCB_DIAG_NO_VEC
                 vec_sweep(ci);   // wavefront 1: vector recursion of this chunk, one stage behind the matrices
 #endif
-            }, [&](int lane, auto nl) {
+            }, [&](int ci, int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
+                const int k1 = k1_of(ci), k0 = imax(k1 - CH + 1, 0);
+                const int nk1 = k0 - 1, nk0 = imax(nk1 - CH + 1, 0), nkl = imax(nk0 - 1, 0);   // chunk ci+1
+                const int pk1 = k1 + CH, pk0 = k1 + 1;                                          // chunk ci-1
+                // chunk ci+1's inputs go where chunk ci-1's were: both recursions must be done with chunk ci-1
+                if (ci > 0) ex.await(&sm.prog1, Nl - pk0);
                 if (nk1 >= 0) copy_lanes<WR, O_GQ, W2, WR, true, NL>(vr_of(ci + 1), ex.smem().w.G2, nkl, nk1, lane);
+                if ((lane & (WAVE - 1)) == 0) ex.post_add(&sm.flg[0], 1);
                 if (ci > 0) copy_lanes<WF, FO, W4, WF, false, NL>(vf_of(ci - 1), ex.smem().w.G4, pk0, pk1, lane);
+                // chunk ci-1's factor buffer: stored now; the vector recursion reads its lowest row (P) once more, at
+                // the first stage of chunk ci
+                ex.await(&sm.prog1, Nl - k1);
+                if ((lane & (WAVE - 1)) == 0) ex.post_add(&sm.flg[1], 1);
                 if constexpr (RES) {
                     // copies issued: the first background wavefront follows the recursion and accumulates the chunk
                     // transition matrix Phi_c <- Phi_c Acl_k (lane i < 12 holds row i in registers), k descending
@@ -1349,8 +1369,10 @@ struct Engine {
 #endif
                 }
             });
-            PROF_ADD(PF_SEQ_FACT, ts);
-            if (k0 == 0) copy_rect<WF, FO, W4, WF, false>(vf, ex.smem().w.G4, k0, k1);   // last chunk: nothing left to hide the store behind
+        PROF_ADD(PF_SEQ_FACT, ts);
+        {   // last chunk: nothing left to hide the store behind
+            const int k1 = k1_of(nwin - 1);
+            copy_rect<WF, FO, W4, WF, false>(vf_of(nwin - 1), ex.smem().w.G4, 0, k1);
         }
         PROF_ADD(PF_FACT, t0);
     }

@@ -141,6 +141,28 @@ struct DevExec {
             __syncthreads();
         }
     }
+    // A loop of `nwin` windows of three roles WITHOUT workgroup barriers between the windows (four wavefronts and more):
+    // every role runs its own loop and the roles meet through LDS counters (post / post_add / await) only; one barrier at
+    // the end.  With fewer wavefronts (roles share a wavefront) each window is an overlap3 with its barrier.
+    static constexpr int BG_WAVES = NWV > 2 ? NWV - 2 : 1;
+    template <class FG, class MID, class BG>
+    __device__ __forceinline__ void pipeline3(int nwin, FG &&fg, MID &&mid, BG &&bg)
+    {
+        if (NWV >= 4) {
+            if (threadIdx.x < WAVE) { for (int ci = 0; ci < nwin; ci++) fg(ci); }
+            else if (threadIdx.x < 2 * WAVE) { for (int ci = 0; ci < nwin; ci++) mid(ci); }
+            else { for (int ci = 0; ci < nwin; ci++) { bg(ci, lane_id() - 2 * WAVE, std::integral_constant<int, WAVE * BG_WAVES>{}); wave_fence(); } }
+            __syncthreads();
+        } else {
+            for (int ci = 0; ci < nwin; ci++)
+                overlap3([&]() { fg(ci); }, [&]() { mid(ci); }, [&](int lane, auto nl) { bg(ci, lane, nl); });
+        }
+    }
+    __device__ __forceinline__ static void post_add(int *flag, int v)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __hip_atomic_fetch_add(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // progress counter between the recursion wavefront and the one following it (LDS, same CU):
     // a wavefront's LDS operations complete in issue order, so data written before post() is
     // visible to whoever has seen the posted value.

@@ -170,7 +170,9 @@ struct Smem {
     Ws w;                  // this instance's workspace pointers: kept here because the engine object lives in
     int n_hor, pool_n;     // scratch memory inside a non-inlined pass (a flat load + full wait per use); LDS is ~10x closer
     int prog;              // progress of the state recursion (last finished stage), Ex::post / await
-    int prog_pad;
+    int prog1;             // progress of the follower recursion (vector half of the factorisation sweep)
+    int flg[2];            // factorisation pipeline: input chunks landed, factor buffers released (counted per background wavefront)
+    int flg_pad;
     alignas(16) double mt2[2][16];     // p_{k+1} + P_{k+1} rb_k hand-over slots (host executor only)
     alignas(16) double pv[2][12];
     alignas(16) double Rt[36];      // R~ = H_uu + Gamma_u + B'MB

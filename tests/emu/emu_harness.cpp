@@ -65,6 +65,14 @@ struct HostExec {
         mid();   // mid and bg may follow fg's progress (post / await): fg has finished here
         for (int l = 0; l < NT; l++) bg(l, std::integral_constant<int, NT>{});
     }
+    static constexpr int BG_WAVES = NWV;    // overlap3 hands every lane to the background role here
+    template <class FG, class MID, class BG>
+    void pipeline3(int nwin, FG &&fg, MID &&mid, BG &&bg)
+    {
+        for (int ci = 0; ci < nwin; ci++)
+            overlap3([&]() { fg(ci); }, [&]() { mid(ci); }, [&](int lane, auto nl) { bg(ci, lane, nl); });
+    }
+    static void post_add(int *flag, int v) { *flag += v; }
     static void post(int *flag, int v) { *flag = v; }
     static void await(int *flag, int v) { if (*flag < v) std::abort(); }
     template <class F>
