@@ -59,7 +59,8 @@ extern "C" {
  * overrides the choice where both apply.  An SQP_RTI bucket of at least as many simulations as the GPU holds wavefronts of
  * the throughput engine (8 per CU) is launched as a work queue over (simulation, MPCB_STREAM_CHUNK = 10 closed-loop steps)
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
- * within 30 s is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
+ * within a bound derived from the work limit of one chunk -- 4 x chunk steps x SQP iterations x QP iterations x (N+1) x 20 us
+ * + 30 s; MPCB_QUEUE_TIMEOUT_S overrides it -- is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
 #define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on, for runs of >= 100 closed-loop steps */
 #define MPCB_STREAM_MIN_BATCH 1408   /* measured crossover at N=100, 600 steps, one MI355X (profiles/r03_engine_sweep.txt): 1280 simulations
                                         741 k (latency engine, two per CU) vs 720 k, 1536: ~745 k vs 826 k steps/s */

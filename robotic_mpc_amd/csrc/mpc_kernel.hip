@@ -284,13 +284,15 @@ __global__ __launch_bounds__(WAVE *NWV, WPE) void mpc_rollout_kernel(Problem pb,
 //     which may have run on any CU: the finishing wavefront releases (stores drained, agent-scope release, progress
 //     counter), the next one polls the counter and acquires (MI355X_MICROARCH.md, hand-off recipe).  An item's
 //     predecessor was popped earlier, so it is running or done: no wavefront ever waits for work nobody has taken.  A
-//     bounded poll (QUEUE_TIMEOUT_TICKS of the 100 MHz clock) turns a broken hand-off into an error flag, never a hang.
+//     bounded poll (`timeout_ticks` of the 100 MHz clock, queue_timeout_ticks below) turns a broken hand-off into an error flag, never a hang.
 //   queue[0] item counter, queue[1] error flag, queue[2 + i] chunks of simulation i done in this launch.
-constexpr long long QUEUE_TIMEOUT_TICKS = 30LL * 100000000LL;
+// The bound is a bug guard, not a schedule: a waiting item's predecessor is always running, so it is sized from the WORK LIMIT of
+// one chunk (queue_timeout_ticks below), never from typical times -- a legitimately slow chunk (full SQP at a long horizon, every
+// QP running to qp_solver_iter_max) must not trip it and take the whole bucket down.
 template <class FT>
 __global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Problem pb, const Robot *__restrict__ rbd, const InstParams *__restrict__ params,
                                                                            double *ws_base, size_t ws_stride, Outputs out, int step0, int step1,
-                                                                           int *queue, int chunk_steps)
+                                                                           int *queue, int chunk_steps, long long timeout_ticks)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool queued = queue != nullptr;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(WAVE, MPCB_STREAM_WPE) void mpc_stream_kernel(Probl
             if (c > 0) {
                 int ok = 1;
                 if (threadIdx.x == 0) {
-                    const long long t_end = (long long)wall_clock64() + QUEUE_TIMEOUT_TICKS;
+                    const long long t_end = (long long)wall_clock64() + timeout_ticks;
                     while (__hip_atomic_load(&queue[2 + inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) {
                         if ((long long)wall_clock64() > t_end || __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                             __hip_atomic_store(&queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -360,13 +362,14 @@ __global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, 
             st[j] += tk * e * e;                                     // :368
         }
     }
-    double sq = 0, qp = 0, fail = 0, kkt = 0, tsol = 0, tpl = 0;
+    double sq = 0, qp = 0, fail = 0, kkt = 0, tsol = 0, tpl = 0, anynan = 0;   // (np.max propagates NaN, fmax drops it: flag)
     for (int i = lane; i < Nsim; i += WAVE) {
         const size_t k = (size_t)inst * Nsim + i;
         sq += o.sqp_iter[k]; qp += o.qp_iter[k]; fail += o.status[k] != 0 ? 1.0 : 0.0;
         tsol += o.solver_time[k]; tpl += o.plant_time[k];
         const double *r = o.residuals + k * 4;
         kkt = fmax(kkt, fmax(fmax(r[0], r[1]), fmax(r[2], r[3])));    // :402
+        anynan += (r[0] != r[0] || r[1] != r[1] || r[2] != r[2] || r[3] != r[3]) ? 1.0 : 0.0;
     }
     using X = DevExec<1>;
     double wsum = 0.0;
@@ -378,6 +381,8 @@ __global__ __launch_bounds__(WAVE) void mpc_summary_kernel(int batch, int Nsim, 
     }
     sq = X::wave_reduce(sq, X::OpSum()); qp = X::wave_reduce(qp, X::OpSum()); fail = X::wave_reduce(fail, X::OpSum());
     tsol = X::wave_reduce(tsol, X::OpSum()); tpl = X::wave_reduce(tpl, X::OpSum()); kkt = X::wave_reduce(kkt, X::OpMax());
+    anynan = X::wave_reduce(anynan, X::OpSum());
+    if (anynan > 0) kkt = __builtin_nan("");     // a diverged simulation (NaN residuals) must show in max_kkt_residual, as in the reference
     if (lane == 0) {
         double *s = summary + (size_t)inst * MPCB_NSUMMARY;
         for (int j = 0; j < 5; j++) { s[j] = sqrt(se[j] / T1); s[5 + j] = st[j] * dt; }
@@ -622,6 +627,18 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
     return MPCB_OK;
 }
 
+// Hand-off timeout of the work-queue launch in ticks of the 100 MHz clock: the most work one chunk of one simulation can be
+// (chunk_steps x SQP iterations x (interior-point iterations + 1) x (N + 1) stage-iterations), priced at 20 us per stage-iteration --
+// more than 10x what a wavefront sharing its SIMD takes, profiling and eight buckets in flight included -- times 4, plus 30 s.
+// MPCB_QUEUE_TIMEOUT_S overrides it (seconds).
+static long long queue_timeout_ticks(const Problem &pb, int chunk_steps)
+{
+    if (const char *e = getenv("MPCB_QUEUE_TIMEOUT_S")) { const double v = atof(e); if (v > 0) return (long long)(v * 1e8); }
+    const double sqp = pb.solver_type == MPCB_SOLVER_SQP ? (double)(pb.max_iter > 1 ? pb.max_iter : 1) : 1.0;
+    const double work_s = (double)(chunk_steps > 1 ? chunk_steps : 1) * sqp * (double)(pb.qp_iter_max + 1) * (double)(pb.N + 1) * 20e-6;
+    return (long long)((4.0 * work_s + 30.0) * 1e8);
+}
+
 int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, void *stream)
 {
     if (!h) return MPCB_EINVAL;
@@ -662,14 +679,15 @@ int mpcb_rollout(mpcb_handle *h, int step0, int step1, const mpcb_result *o, voi
             queue = h->d_queue;
         }
         h->queue_used = queued;
+        const long long qticks = queue_timeout_ticks(h->pb, chunk);
         HIPCHK(h, hipEventRecord(h->ev0, s));
         const dim3 sgrid((unsigned)(queued ? nslots : h->pb.batch));
         if (h->pb.precision == MPCB_PRECISION_FP32_RICCATI)
             hipLaunchKernelGGL(mpc_stream_kernel<float>, sgrid, dim3(WAVE), 0, s, h->pb, h->d_rb, h->d_params, h->d_ws, h->ws_stride, out,
-                               step0, step1, queue, chunk);
+                               step0, step1, queue, chunk, qticks);
         else
             hipLaunchKernelGGL(mpc_stream_kernel<double>, sgrid, dim3(WAVE), 0, s, h->pb, h->d_rb, h->d_params, h->d_ws, h->ws_stride, out,
-                               step0, step1, queue, chunk);
+                               step0, step1, queue, chunk, qticks);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev1, s));
         h->last_stream = s;

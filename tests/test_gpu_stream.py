@@ -312,3 +312,36 @@ def test_work_queue_launch_equals_one_workgroup_per_simulation(monkeypatch, ur10
         if k not in ("solver_time", "plant_time"):
             np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
     assert (outs[1]["status"] == 0).all()
+
+
+def test_work_queue_waits_for_a_legitimately_slow_simulation(monkeypatch, ur10):
+    """the hand-off timeout is a bug guard sized from the WORK LIMIT of a chunk, not from typical times.  One
+    simulation of the batch has bounds it cannot meet (full SQP: QPs running into qp_solver_iter_max, failed steps) and
+    does about twice the interior-point work of its neighbours; the queued launch -- two wavefronts, chunks of 3 steps, so
+    that the slow simulation's next chunk always waits for its predecessor -- must neither time out nor differ from the
+    plain launch.  With MPCB_QUEUE_TIMEOUT_S set absurdly low the SAME run is reported as a failed hand-off by mpcb_sync
+    (an error, never a hang, never silently incomplete logs)."""
+    from robotic_mpc_amd import engine
+
+    monkeypatch.setenv("MPCB_ENGINE", "stream")
+    so = {"nlp_solver_type": "SQP", "nlp_solver_max_iter": 12, "qp_solver_iter_max": 50}
+    cfgs = _jitter(5, seed=21, prediction_horizon=40, simulation_time=0.24, solver_options=so)
+    slow = _cfg(prediction_horizon=40, simulation_time=0.24, solver_options=so,
+                qdot_min=np.full(6, -0.02), qdot_max=np.full(6, 0.02), q_min=np.full(6, -0.5), q_max=np.full(6, 0.5))
+    cfgs = [slow] + cfgs
+    runs = []
+    for slots, chunk in (("0", "0"), ("2", "3")):
+        monkeypatch.setenv("MPCB_STREAM_SLOTS", slots)
+        monkeypatch.setenv("MPCB_STREAM_CHUNK", chunk)
+        e = engine.MpcBatchEngine(0)
+        runs.append(e.run(cfgs, ur10))
+        e.close()
+    for k in runs[0]:
+        if k not in ("solver_time", "plant_time"):
+            np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
+    assert runs[0]["qp_iter"][0].sum() > 1.5 * runs[0]["qp_iter"][1:].sum(axis=1).max()   # it IS slower than the others (its chunks are waited for)
+    monkeypatch.setenv("MPCB_QUEUE_TIMEOUT_S", "1e-7")
+    e = engine.MpcBatchEngine(0)
+    with pytest.raises(engine.EngineError, match="hand-off"):
+        e.run(cfgs, ur10)
+    e.close()
