@@ -298,7 +298,13 @@ struct Engine {
         int scr_n, L;
     };
     static constexpr int RS_GROUPS = (NT / 16) < 16 ? (NT / 16) : 16;
-    static constexpr int RS_ROUNDS = 5;     // items a lane prefetches at a time (RS_ROUNDS * NT items per batch)
+    // items a lane holds in flight per batch, sized so that ONE batch covers N ~ 105 at this lane count (more lanes: fewer items each,
+    // and the 8-wavefront geometry has half the registers)
+    static constexpr int rounds_for(int items_per_stage)
+    {
+        return NT >= 256 ? (items_per_stage * 106 + NT - 1) / NT : (items_per_stage * 106 + 255) / 256;   // (1-2 wavefronts: more batches instead)
+    }
+    static constexpr int RS_ROUNDS = rounds_for(12);
     static constexpr int RS_PER_STAGE = 72 + 6 + 12 + 12;
     MPC_HD ResMap res_map() const
     {
@@ -741,7 +747,7 @@ struct Engine {
         ex.wpar([&](int lane) { n_g.at(lane) = 0; n_b.at(lane) = 0; n_d.at(lane) = 0; n_m.at(lane) = 0; n_mu.at(lane) = 0; n_c.at(lane) = 0; });
         if (mode == 1) {
             // dw (18) | pi (12) += a * step: G1 columns [18, 48) <- G3 columns [66, 96); dpi of multiplier k -> k+1 sits with stage k+1
-            constexpr int R = 6, IPS = 15;
+            constexpr int IPS = 15, R = rounds_for(IPS);
             const int items = NS * IPS;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
@@ -774,7 +780,7 @@ struct Engine {
         }
         {
             // lam (24) | t (24): G1 columns [48, 96) <- G3 columns [96, 144); q = column - 48: lam lower 12 | upper 12 | t lower | upper
-            constexpr int R = 10, IPS = 24;
+            constexpr int IPS = 24, R = rounds_for(IPS);
             const int items = NS * IPS;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
@@ -817,7 +823,7 @@ struct Engine {
         PROF_T0(ty);
         // ---------------------------------------------------------------- Y: items (k < N, i < 5)
         {
-            constexpr int R = 2;
+            constexpr int R = rounds_for(NTASK);
             const int items = Nl * NTASK;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
@@ -859,7 +865,7 @@ struct Engine {
         PROF_T0(tz);
         // ---------------------------------------------------------------- S: joint items (k, j < 6), two kinds
         {
-            constexpr int R = 3;
+            constexpr int R = rounds_for(6);
             const int items = NS * 6;
             const double dt = P.dt, lm = P.lm;
             // bound part of a bounded component ci (value `val`, step `dv`): returns gt, updates rg, writes rd | rm | Gamma
@@ -1939,7 +1945,7 @@ struct Engine {
         double *X = rm.scr, *xch = X + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
         const int items = NS * 6;      // joint items (k, j): the bounded components u_j and q_j together
         const int items_pi = NS * NB;  // dpi items (k, state component)
-        constexpr int R = 3;
+        constexpr int R = rounds_for(6);
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
         typename Ex::template PerLane<double> ld[R][16];
         typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
