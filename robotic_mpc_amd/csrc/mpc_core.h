@@ -30,6 +30,7 @@
 // step lengths, corrector + backward solve, forward sweep + step lengths, update + residuals.
 #pragma once
 #include "mpc_kin.h"
+#include "mpc_ipm.h"
 
 // 16-way manual unrolling with individually named registers (see Engine::copy_lanes)
 #define MPC_REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
@@ -82,7 +83,7 @@ typedef double D2 __attribute__((ext_vector_type(2)));
 
 // ---- bound bookkeeping (trajectory_optimizer.py:164-171: lbu on stages 0..N-1, lbx on
 // q of stages 1..N-1; x_0 is fixed by lbx_0 = ubx_0, simulator.py:210-211) -------------
-MPC_HD bool has_comp(int N, int k, int j) { return j < 6 ? (k < N) : (k >= 1 && k < N); }
+using ipm::has_comp;
 MPC_HD double bnd_lo(const InstParams &P, int j) { return j < 6 ? P.umin[j] : P.qmin[j - 6]; }
 MPC_HD double bnd_hi(const InstParams &P, int j) { return j < 6 ? P.umax[j] : P.qmax[j - 6]; }
 MPC_HD int imin(int a, int b) { return a < b ? a : b; }
@@ -96,21 +97,6 @@ MPC_HD int mul24(int a, int b)
     return __mul24(a, b);
 #else
     return a * b;
-#endif
-}
-
-// 1/d for the LDL' pivots and the slack divisions of the interior-point formulas: hardware reciprocal seed (measured 4.6e-8 relative on gfx950,
-// scripts/microbench/rcptest.hip) + one third-order correction x (1 + e + e^2), e = 1 - d x:
-// three dependent FMAs to full fp64 accuracy instead of the ~40-instruction IEEE division on the
-// sequential critical path.
-MPC_HD double fast_rcp(double d)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double x = __builtin_amdgcn_rcp(d);
-    const double e = fma(-d, x, 1.0);
-    return fma(x, fma(e, e, e), x);
-#else
-    return 1.0 / d;
 #endif
 }
 
@@ -578,17 +564,15 @@ struct Engine {
                     double *lam = v1 + (size_t)s * L1 + O_QLAM, *t = v1 + (size_t)s * L1 + O_QT;
                     const double *dl = v3d + (size_t)s * W3D + 30, *dt = v3d + (size_t)s * W3D + 54;
                     if (mode == 0) {
-                        if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
-                        else { lam[j] = 0.0; t[j] = 1.0; }
-                        if (bhi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); }
-                        else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                        lam[j] = ipm::warm_lam(blo, lam[j]); t[j] = ipm::warm_t(blo, t[j]);
+                        lam[12 + j] = ipm::warm_lam(bhi, lam[12 + j]); t[12 + j] = ipm::warm_t(bhi, t[12 + j]);
                         ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
                     } else {
                         // all loads first (see corrector_bwd_pass)
                         const double l0 = lam[j], t0_ = t[j], l1 = lam[12 + j], t1_ = t[12 + j];
                         const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
-                        if (blo) { lam[j] = fmax(l0 + a * d0, 1e-16); t[j] = fmax(t0_ + a * e0, 1e-16); }
-                        if (bhi) { lam[12 + j] = fmax(l1 + a * d1, 1e-16); t[12 + j] = fmax(t1_ + a * e1, 1e-16); }
+                        lam[j] = ipm::step_floor(blo, l0, a, d0); t[j] = ipm::step_floor(blo, t0_, a, e0);
+                        lam[12 + j] = ipm::step_floor(bhi, l1, a, d1); t[12 + j] = ipm::step_floor(bhi, t1_, a, e1);
                     }
                 }
                 if (mode == 0) {
@@ -804,11 +788,10 @@ struct Engine {
                             const bool on0 = ok && m.x != 0.0, on1 = ok && m.y != 0.0;
                             D2 v = cur[r];
                             if (mode == 1) {
-                                const double n0 = fmax(v.x + a * stp[r].x, 1e-16), n1 = fmax(v.y + a * stp[r].y, 1e-16);
-                                v.x = on0 ? n0 : v.x; v.y = on1 ? n1 : v.y;
+                                v.x = ipm::step_floor(on0, v.x, a, stp[r].x); v.y = ipm::step_floor(on1, v.y, a, stp[r].y);
                             } else {
-                                const double off = is_t ? 1.0 : 0.0;
-                                v.x = on0 ? fmax(v.x, 0.1) : off; v.y = on1 ? fmax(v.y, 0.1) : off;
+                                v.x = is_t ? ipm::warm_t(on0, v.x) : ipm::warm_lam(on0, v.x);
+                                v.y = is_t ? ipm::warm_t(on1, v.y) : ipm::warm_lam(on1, v.y);
                                 ncl += (on0 && !is_t ? 1.0 : 0.0) + (on1 && !is_t ? 1.0 : 0.0);
                             }
                             *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QLAM + q) = v;
@@ -1461,10 +1444,9 @@ struct Engine {
                     const double dll = r3[C_DLAM + j], dtl = r3[C_DT + j], dlu = r3[C_DLAM + 12 + j], dtu = r3[C_DT + 12 + j];
                     const double rdl = r3[18 + j], rdu = r3[18 + 12 + j];
                     double gt = r3[j];
-                    const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
-                    const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
-                    gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
-                    gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                    double rml, rmu;
+                    gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
+                    gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
                     if (hc) vgr[(size_t)s * WGR + j] = gt;
                     rmo[j] = rml; rmo[12 + j] = rmu;
                 }
@@ -1724,21 +1706,9 @@ struct Engine {
                             const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
                             const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
                             const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
-                            double dtl = 0, dll = 0, dtu = 0, dlu = 0;
-                            if (blo) {
-                                dtl = dv + rdl;
-                                dll = -(rml + ll * dtl) * fast_rcp(tl);
-                                if (dll < 0 && ll + al * dll < 0) al = -ll * fast_rcp(dll);
-                                if (dtl < 0 && tl + al * dtl < 0) al = -tl * fast_rcp(dtl);
-                                a0 += ll * tl; a1 += ll * dtl + tl * dll; a2 += dll * dtl;
-                            }
-                            if (bhi) {
-                                dtu = -dv + rdu;
-                                dlu = -(rmu + lu * dtu) * fast_rcp(tu);
-                                if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
-                                if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
-                                a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
-                            }
+                            double dtl, dll, dtu, dlu;
+                            ipm::lam_t_side(blo, dv, ll, tl, rdl, rml, al, a0, a1, a2, dtl, dll);
+                            ipm::lam_t_side(bhi, -dv, lu, tu, rdu, rmu, al, a0, a1, a2, dtu, dlu);
                             o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
                             o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
                         }
@@ -1977,17 +1947,8 @@ struct Engine {
             if (base > 0) issue(base);
             ex.wpar([&](int lane) {
                 double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
-                // one bound side (HPIPM compute_lam_t + the step-length and centering contributions), branch-free: an absent
-                // side holds lam = 0, t = 1, rd = rm = 0 and `on` zeroes its dt, so its dlam and all its sums vanish
                 auto side = [&](bool on, double sdv, double l, double t, double rd, double rmv, double &dt_o, double &dl_o) {
-                    const double dt = on ? sdv + rd : 0.0;
-                    const double dl = on ? -(rmv + l * dt) * fast_rcp(t) : 0.0;
-                    const double c1 = -l * fast_rcp(dl);
-                    al = (dl < 0 && l + al * dl < 0) ? c1 : al;
-                    const double c2 = -t * fast_rcp(dt);
-                    al = (dt < 0 && t + al * dt < 0) ? c2 : al;
-                    a0 += l * t; a1 += l * dt + t * dl; a2 += dl * dt;
-                    dt_o = dt; dl_o = dl;
+                    ipm::lam_t_side(on, sdv, l, t, rd, rmv, al, a0, a1, a2, dt_o, dl_o);   // (mpc_ipm.h: compute_lam_t, step length, centering sums)
                 };
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -2111,10 +2072,9 @@ struct Engine {
                         const double ll = v[r][0], lu = v[r][1], tl = v[r][2], tu = v[r][3];
                         const double dll = v[r][4], dlu = v[r][5], dtl = v[r][6], dtu = v[r][7], rdl = v[r][8], rdu = v[r][9];
                         double gt = v[r][10];
-                        const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
-                        const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
-                        gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
-                        gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                        double rml, rmu;
+                        gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
+                        gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
                         GT[(size_t)k * 18 + j] = gt;
                         RW[(size_t)k * 12 + j] = v[r][11];
                         gst(G3 + (size_t)k * W3 + O_RM + j, rml); gst(G3 + (size_t)k * W3 + O_RM + 12 + j, rmu);
@@ -2238,14 +2198,13 @@ struct Engine {
                 const double S0 = res ? ex.uni(sm.cen[1]) : ex.get1(sm.red[1]), S1 = res ? ex.uni(sm.cen[2]) : ex.get1(sm.red[2]),
                              S2 = res ? ex.uni(sm.cen[3]) : ex.get1(sm.red[3]);
                 const double mu_aff = (S0 + a_aff * (S1 + a_aff * S2)) / nc;
-                const double tmp = mu_aff / mu;
-                const double sigma = tmp * tmp * tmp;
+                const double sigma = ipm::sigma(mu_aff, mu);
                 if (res) { corr_resident(sigma * mu); alpha = fwd_resident<false>(); }
                 else { corrector_bwd_pass(sigma * mu); alpha = forward_step_pass<false>(); }
             } else {
                 alpha = a_aff;
             }
-            const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
+            const double a = ipm::step_scale(alpha);
 #ifdef MPCB_OLD_RESIDUAL
             residual_pass(1, a);
 #else

@@ -501,18 +501,16 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             const bool blo = hc && lj_lo, bhi = hc && lj_hi;
             double *lam = row + O_QLAM, *t = row + O_QT;
             if (!STEP) {
-                if (blo) { lam[j] = fmax(lam[j], 0.1); t[j] = fmax(t[j], 0.1); }
-                else { lam[j] = 0.0; t[j] = 1.0; }
-                if (bhi) { lam[12 + j] = fmax(lam[12 + j], 0.1); t[12 + j] = fmax(t[12 + j], 0.1); }
-                else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                lam[j] = ipm::warm_lam(blo, lam[j]); t[j] = ipm::warm_t(blo, t[j]);
+                lam[12 + j] = ipm::warm_lam(bhi, lam[12 + j]); t[12 + j] = ipm::warm_t(bhi, t[12 + j]);
                 ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
             } else {
                 const double *dl = row + I_D + 30, *dt = row + I_D + 54;
                 const double l0 = lam[j], t0 = t[j], l1 = lam[12 + j], t1 = t[12 + j];
                 const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
                 // (selects, not branches: every exec-mask branch costs scalar instructions and a bubble)
-                lam[j] = blo ? fmax(l0 + a * d0, 1e-16) : l0; t[j] = blo ? fmax(t0 + a * e0, 1e-16) : t0;
-                lam[12 + j] = bhi ? fmax(l1 + a * d1, 1e-16) : l1; t[12 + j] = bhi ? fmax(t1 + a * e1, 1e-16) : t1;
+                lam[j] = ipm::step_floor(blo, l0, a, d0); t[j] = ipm::step_floor(blo, t0, a, e0);
+                lam[12 + j] = ipm::step_floor(bhi, l1, a, d1); t[12 + j] = ipm::step_floor(bhi, t1, a, e1);
             }
         }
     };
@@ -583,8 +581,8 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
                     const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
                     const bool blo = hc && lj_lo, bhi = hc && lj_hi;
                     double *lam = nxt + O_QLAM, *t = nxt + O_QT;
-                    lam[j] = blo ? fmax(l0 + a * d0, 1e-16) : l0; t[j] = blo ? fmax(t0 + a * e0, 1e-16) : t0;
-                    lam[12 + j] = bhi ? fmax(l1 + a * d1, 1e-16) : l1; t[12 + j] = bhi ? fmax(t1 + a * e1, 1e-16) : t1;
+                    lam[j] = ipm::step_floor(blo, l0, a, d0); t[j] = ipm::step_floor(blo, t0, a, e0);
+                    lam[12 + j] = ipm::step_floor(bhi, l1, a, d1); t[12 + j] = ipm::step_floor(bhi, t1, a, e1);
                 } else if (lane >= 32 && lane < 44) {
                     cur[O_QPI + lane - 32] = p1 + a * u2;
                 }
@@ -604,10 +602,8 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
                     const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
                     const bool blo = hc && lj_lo, bhi = hc && lj_hi;
                     double *lam = nxt + O_QLAM, *t = nxt + O_QT;
-                    if (blo) { lam[j] = fmax(l0, 0.1); t[j] = fmax(t0, 0.1); }
-                    else { lam[j] = 0.0; t[j] = 1.0; }
-                    if (bhi) { lam[12 + j] = fmax(l1, 0.1); t[12 + j] = fmax(t1, 0.1); }
-                    else { lam[12 + j] = 0.0; t[12 + j] = 1.0; }
+                    lam[j] = ipm::warm_lam(blo, l0); t[j] = ipm::warm_t(blo, t0);
+                    lam[12 + j] = ipm::warm_lam(bhi, l1); t[12 + j] = ipm::warm_t(bhi, t1);
                     ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
                 }
             }
@@ -1142,10 +1138,9 @@ SE_PASS void corrector_pass(double sigma_mu)
         const double dll = dl[j], dtl = dl[24 + j], dlu = dl[12 + j], dtu = dl[36 + j];
         const double rdl = r3[18 + j], rdu = r3[18 + 12 + j];
         double gt = r3[j];
-        const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
-        const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
-        gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
-        gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+        double rml, rmu;
+        gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
+        gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
         og[j] = hc ? gt : gtb[j];
         if (j < 6) og[12 + j] = gtb[12 + j];
         rmo[j] = rml; rmo[12 + j] = rmu;
@@ -1185,10 +1180,9 @@ SE_PASS void corrector_pass(double sigma_mu)
                 double *og = sm.gtc[kr & 1], *rmo = sm.out[kr & 1];
                 const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
                 const bool blo = hc && jc_lo, bhi = hc && jc_hi;
-                const double rml = blo ? ll * tl + dll * dtl - sigma_mu : 0.0;
-                const double rmu = bhi ? lu * tu + dlu * dtu - sigma_mu : 0.0;
-                gt += blo ? (rml + ll * rdl) * fast_rcp(tl) : 0.0;
-                gt -= bhi ? (rmu + lu * rdu) * fast_rcp(tu) : 0.0;
+                double rml, rmu;
+                gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
+                gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
                 og[j] = hc ? gt : gb0;
                 if (j < 6) og[12 + j] = gb1;
                 rmo[j] = rml; rmo[12 + j] = rmu;
@@ -1283,8 +1277,7 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr
             SPROF_ADD(1, ta);
             const double a_aff = unid(sa.alpha);
             const double mu_aff = (unid(sa.S0) + a_aff * (unid(sa.S1) + a_aff * unid(sa.S2))) / nc;
-            const double tmp = mu_aff / mu;
-            const double sigma = tmp * tmp * tmp;
+            const double sigma = ipm::sigma(mu_aff, mu);
             SPROF_T0(tc);
             corrector_pass<FT>(sigma * mu);
             SPROF_ADD(2, tc);
@@ -1294,7 +1287,7 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr
         } else {
             alpha = unid(forward_pass<FT, false>().alpha);
         }
-        const double a = alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999);
+        const double a = ipm::step_scale(alpha);
         SPROF_T0(tr);
         r = residual_pass<1>(a);
         SPROF_ADD(4, tr);
