@@ -1938,7 +1938,22 @@ struct Engine {
                 if (base == 0) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; }
             });
         };
+        // final sweep: row j of the packed P_k for the dpi items, straight from HBM (issued with the other operands)
+        constexpr int RP = AFFINE ? 1 : RS_ROUNDS;
+        typename Ex::template PerLane<double> pmr[RP][12];
+        auto issue_pi = [&](int base) {
+            ex.wpar([&](int lane) {
+#pragma unroll
+                for (int r = 0; r < RP; r++) {
+                    const int e = imin(base + r * NT + lane, items_pi - 1), k = e / NB, j = e - k * NB;
+                    const double *g4 = G4 + (size_t)k * W4 + O_PM;
+#pragma unroll
+                    for (int i = 0; i < NX; i++) pmr[r][i].at(lane) = gld(g4 + tri_sym(j, i));
+                }
+            });
+        };
         issue(0);
+        if (!AFFINE) issue_pi(0);
         PROF_T0(ts);
         rs_recursion<true>(rm, X, xch, xs);
         ex.barrier();
@@ -1990,16 +2005,9 @@ struct Engine {
             constexpr int R = RS_ROUNDS;
             const int items = items_pi;
             for (int base = 0; base < items; base += R * NT) {
-                // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1}): row j of the packed P_k from HBM
+                // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1})
+                if (base > 0) issue_pi(base);
                 ex.wpar([&](int lane) {
-                    double pm[R][12];
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
-                        const double *g4 = G4 + (size_t)k * W4 + O_PM;
-#pragma unroll
-                        for (int i = 0; i < NX; i++) pm[r][i] = gld(g4 + tri_sym(j, i));
-                    }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int e = base + r * NT + lane;
@@ -2010,7 +2018,7 @@ struct Engine {
                             if (k >= 1) {
                                 double s0 = rm.P[(size_t)k * 12 + j], s1 = 0.0;
 #pragma unroll
-                                for (int i = 0; i < NX; i += 2) { s0 += pm[r][i] * dxk[i]; s1 += pm[r][i + 1] * dxk[i + 1]; }
+                                for (int i = 0; i < NX; i += 2) { s0 += pmr[r][i].at(lane) * dxk[i]; s1 += pmr[r][i + 1].at(lane) * dxk[i + 1]; }
                                 v = s0 + s1;
                             }
                             gst(G3 + (size_t)k * W3 + O_DPI + j, v);

@@ -615,6 +615,14 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         // one simulation per CU: 4 wavefronts, 512 registers; beyond: two 4-wavefront simulations per CU at 256 registers
         int nw = wpc <= 2 ? 4 : 1;
         int wpe = wpc == 2 ? 2 : 1;
+        // one simulation per CU AND the factor LDS-resident (Engine::resident_ok): every pass but the factorisation sweep is item- or
+        // chunk-parallel then, and a second wavefront per SIMD buys issue slots (665 k vs 651 k steps/s on configs[1]); the streaming
+        // path's role layout prefers 4 (round 1).
+        {
+            const int NS = p->N + 1, scr = h->pool_doubles - (NS * 102 + 16 * 144);
+            // (measured: N = 100 665 k vs 651 k; N = 50 1.045 M vs 1.054 M; N = 20 1.59 M vs 1.68 M -- short horizons have too few items)
+            if (wpc == 1 && p->N >= 80 && scr >= 4096 && scr >= NS * 30 + 2 * 16 * 12 + 16) nw = 8;
+        }
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }
         if (const char *e3 = getenv("MPCB_WPE")) { if (atoi(e3) == 2 && nw == 4) wpe = 2; else if (atoi(e3) == 1) wpe = 1; }
         h->waves_per_sim = nw;
