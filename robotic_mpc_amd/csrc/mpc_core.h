@@ -1268,16 +1268,20 @@ struct Engine {
                         if (k > 0) {
                             const double *St = sm.St2[sb];
                             const double *gq = ric, *gv = ric + 30;
-                            double sa[6], sva[6], kb[6], kvb[6];
-#pragma unroll
-                            for (int m = 0; m < 6; m++) {
-                                sa[m] = St[m * 12 + f.a]; sva[m] = St[m * 12 + 6 + f.a];
-                                kb[m] = kk[m * 12 + f.b]; kvb[m] = kk[m * 12 + 6 + f.b];
-                            }
+                            // Operands in the order they can be used (LDS returns in issue order): the linearisation and S~ do not
+                            // depend on phase B, K does -- its write -> read round trip runs under the K-independent part of P_k.
                             const double ga0 = gq[f.a], ga1 = gq[6 + f.a], ga2 = gq[12 + f.a], ga3 = gq[18 + f.a], ga4 = gq[24 + f.a];
                             const double gb0 = gq[f.b], gb1 = gq[6 + f.b], gb2 = gq[12 + f.b], gb3 = gq[18 + f.b], gb4 = gq[24 + f.b];
                             const double gva = gv[f.a], gvb = gv[f.b];
                             const double gam_q = gam[6 + f.a], gam_u = ricd[36 + f.a];   // unconditional (see next_stage)
+                            double sa[6], sva[6], kb[6], kvb[6];
+#pragma unroll
+                            for (int m = 0; m < 6; m++) { sa[m] = St[m * 12 + f.a]; sva[m] = St[m * 12 + 6 + f.a]; }
+#pragma unroll
+                            for (int m = 0; m < 6; m++) { kb[m] = kk[m * 12 + f.b]; kvb[m] = kk[m * 12 + 6 + f.b]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                            asm volatile("" ::: "memory");    // keep that issue order
+#endif
                             double pqq = f.qqq + (dw0 * ga0 * gb0 + dw1 * ga1 * gb1 + dw2 * ga2 * gb2 + dw3 * ga3 * gb3 + dw4 * ga4 * gb4) + f.lm_c;
                             double pqv = f.qqv + dw4 * ga4 * gvb;
                             double pvq = f.qvq + dw4 * gva * gb4;
@@ -1289,10 +1293,11 @@ struct Engine {
                                 pvq -= sva[m] * kb[m]; pvv -= sva[m] * kvb[m];
                             }
                             f.mqq = pqq; f.mqv = pqv; f.mvq = pvq; f.mvv = pvv;
+                            // R~, S~ of stage k-1 first (the next phase B waits for them), then the record of P_k
+                            next_stage(lane, f, gam_u, sb ^ 1);
                             // packed upper triangle: (a,b) of the qq and vv blocks only for a <= b, the qv block in full
                             if (f.a <= f.b) { fac[O_PM + f.oqq] = pqq; fac[O_PM + f.ovv] = pvv; }
                             fac[O_PM + f.oqv] = pqv;
-                            next_stage(lane, f, gam_u, sb ^ 1);
                         }
                     }
                     if (lane == 0) ex.post(&sm.prog, Nl - k);   // K_k, R~^-1_k, P_k are in LDS
