@@ -48,6 +48,11 @@ constexpr int L1 = 98;
 // lane per stage (every lane touches the same column of a different stage): stride 62
 constexpr int L2N = 62;
 
+#ifdef MPCB_OLD_NLP_PASS
+#define NLP_PASS nlp_pass
+#else
+#define NLP_PASS nlp_direct
+#endif
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
 #define PROF_ADD(i, v) prof[i] += ex.clock() - v
@@ -451,6 +456,216 @@ struct Engine {
                     copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, ex.smem().w.G1, k0, k1, lane);
                     if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, ex.smem().w.G5, k0, k1, lane);
                 }
+                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
+            });
+        }
+        if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
+        PROF_ADD(PF_NLP, t0);
+        return cost;
+    }
+
+    // The same pass, item-parallel (replaces nlp_pass; any horizon): the iterate is updated IN PLACE in HBM by 16-byte items, every
+    // lane linearises one stage from operands it loads itself, and the residual norms are joint items (u_j, q_j, v_j together) --
+    // no staging of the 96-column iterate record through LDS (81 KB per pass at N = 100), no copy-back.  The linearisation records
+    // (60 doubles per stage) collect in LDS and leave with one coalesced store.
+    MPC_PASS double nlp_direct(double alpha, bool do_update, bool sqp_mult, double *res4)
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const Robot &rb = sm.rb;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        double *const G1 = ex.smem().w.G1, *const G5 = ex.smem().w.G5;
+        // LDS: the linearisation records of as many stages as fit (row stride L2N: lane <-> stage accesses without bank aliasing)
+        const int CH = ex.uni(imax(1, imin(ex.smem().pool_n / L2N, NS)));
+        double *const v2 = ex.pool();
+        if (do_update) {
+            // (X | U) += alpha * (dx | du): G1 columns [0, 18) <- columns [24, 36) | [18, 24); SQP: multipliers blend towards the QP's
+            constexpr int IPS = 9, R = rounds_for(IPS);
+            const int items = NS * IPS;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    D2 cur[R], stp[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                        const double *g1 = G1 + (size_t)k * W1;
+                        cur[r] = *(MPC_GLOBAL const D2 *)(g1 + c);
+                        stp[r] = *(MPC_GLOBAL const D2 *)(g1 + O_QW + (c < 12 ? 6 + c : c - 12));
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / IPS, c = 2 * (e - k * IPS);
+                            const double aa = (c >= 12 && k >= Nl) ? 0.0 : alpha;   // no input at stage N
+                            D2 v = cur[r];
+                            v.x += aa * stp[r].x; v.y += aa * stp[r].y;
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + c) = v;
+                        }
+                    }
+                });
+            }
+            if (sqp_mult) {
+                // NPI | NLAM | NT (G5 columns [0, 60))  <-  blend towards QPI | QLAM | QT (G1 columns [36, 96))
+                constexpr int IPS5 = 30, R5 = rounds_for(IPS5);
+                const int items5 = NS * IPS5;
+                for (int base = 0; base < items5; base += R5 * NT) {
+                    ex.wpar([&](int lane) {
+                        D2 cur[R5], qp[R5];
+#pragma unroll
+                        for (int r = 0; r < R5; r++) {
+                            const int e = imin(base + r * NT + lane, items5 - 1), k = e / IPS5, c = 2 * (e - k * IPS5);
+                            cur[r] = *(MPC_GLOBAL const D2 *)(G5 + (size_t)k * W5 + c);
+                            qp[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * W1 + O_QPI + c);
+                        }
+#pragma unroll
+                        for (int r = 0; r < R5; r++) {
+                            const int e = base + r * NT + lane;
+                            if (e < items5) {
+                                const int k = e / IPS5, c = 2 * (e - k * IPS5);
+                                D2 v = cur[r];
+                                v.x += alpha * (qp[r].x - v.x); v.y += alpha * (qp[r].y - v.y);
+                                *(MPC_GLOBAL D2 *)(G5 + (size_t)k * W5 + c) = v;
+                            }
+                        }
+                    });
+                }
+            }
+            ex.barrier();
+        }
+        double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
+        for (int k0 = 0; k0 <= Nl; k0 += CH) {
+            const int k1 = imin(k0 + CH - 1, Nl);
+            // ---- linearise: lane <-> stage
+            ex.par([&](int lane) {
+                double csum = 0.0;
+                for (int k = k0 + lane; k <= k1; k += NT) {
+                    double *rec = v2 + (size_t)(k - k0) * L2N;
+                    if (k < Nl) {
+                        const double *g1 = G1 + (size_t)k * W1;
+                        double xx[12], uu[6], xn[12];
+#pragma unroll
+                        for (int i = 0; i < 12; i++) { xx[i] = gld(g1 + O_X + i); xn[i] = gld(g1 + W1 + O_X + i); }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) uu[i] = gld(g1 + O_U + i);
+                        task_lin<true>(rb, P, xx, xx + 6, rec);
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) {
+                            const double r = rec[O_R + i];
+                            s_ += P.w_task[i] * r * r;
+                            rec[O_Y + i] = P.w_task[i] * r;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const double uj = uu[j], vj = xx[6 + j];
+                            const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
+                            s_ += 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
+                            rec[O_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - xn[j];
+                            rec[O_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - xn[6 + j];
+                        }
+                        csum += 0.5 * P.dt * s_;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
+                    }
+                }
+                ex.put_sum(sm.red[4], lane, csum);
+            });
+            cost += ex.get_sum(sm.red[4]);
+            // ---- residual norms: joint items (k, j < 6): rows u_j, q_j, v_j of the stationarity residual, their bounds, the defect
+            if (res4) {
+                constexpr int R = rounds_for(6);
+                const int items = (k1 - k0 + 1) * 6;
+                typename Ex::template PerLane<double> a_s, a_e, a_i, a_c;
+                ex.wpar([&](int lane) { a_s.at(lane) = 0; a_e.at(lane) = 0; a_i.at(lane) = 0; a_c.at(lane) = 0; });
+                for (int base = 0; base < items; base += R * NT) {
+                    ex.wpar([&](int lane) {
+                        double v[R][15];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = imin(base + r * NT + lane, items - 1), s = e / 6, j = e - s * 6, k = k0 + s, km = imax(k - 1, 0);
+                            const double *g1 = G1 + (size_t)k * W1;
+                            // multipliers: the QP's (RTI) or the blended NLP ones (SQP); both laid out pi 12 | lam 24 | t 24
+                            const double *mk = sqp_mult ? G5 + (size_t)k * W5 : g1 + O_QPI;
+                            const double *mm = sqp_mult ? G5 + (size_t)km * W5 : G1 + (size_t)km * W1 + O_QPI;
+                            v[r][0] = gld(g1 + O_U + j); v[r][1] = gld(g1 + O_X + j); v[r][2] = gld(g1 + O_X + 6 + j);
+                            v[r][3] = gld(mk + j); v[r][4] = gld(mk + 6 + j); v[r][5] = gld(mm + j); v[r][6] = gld(mm + 6 + j);
+                            v[r][7] = gld(mk + 12 + j);  v[r][8] = gld(mk + 24 + j);  v[r][9] = gld(mk + 36 + j);   v[r][10] = gld(mk + 48 + j);   // u_j: lam lo, hi, t lo, hi
+                            v[r][11] = gld(mk + 18 + j); v[r][12] = gld(mk + 30 + j); v[r][13] = gld(mk + 42 + j);  v[r][14] = gld(mk + 54 + j);   // q_j
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = base + r * NT + lane;
+                            if (e < items) {
+                                const int s = e / 6, j = e - s * 6, k = k0 + s;
+                                const double *rec = v2 + (size_t)s * L2N;
+                                const double uj = v[r][0], qj = v[r][1], vj = v[r][2];
+                                const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+                                double as_ = a_s.at(lane), ai_ = a_i.at(lane), ac_ = a_c.at(lane);
+                                auto bound = [&](int ci, double cur, double l_lo, double l_hi, double t_lo, double t_hi, double &val) {
+                                    if (has_comp(Nl, k, ci)) {
+                                        if (bnd_lo(P, ci) > -BOUND_INF) {
+                                            val -= l_lo;
+                                            ai_ = fmax(ai_, fabs((bnd_lo(P, ci) - cur) + t_lo));
+                                            ac_ = fmax(ac_, fabs(l_lo * t_lo));
+                                        }
+                                        if (bnd_hi(P, ci) < BOUND_INF) {
+                                            val += l_hi;
+                                            ai_ = fmax(ai_, fabs((cur - bnd_hi(P, ci)) + t_hi));
+                                            ac_ = fmax(ac_, fabs(l_hi * t_hi));
+                                        }
+                                    }
+                                };
+                                // u_j (stat_cls<0>, no step)
+                                double ru = 0.0;
+                                if (k < Nl) {
+                                    ru = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
+                                    ru += P.b1[j] * v[r][3] + P.b2[j] * v[r][4];
+                                }
+                                bound(j, uj, v[r][7], v[r][8], v[r][9], v[r][10], ru);
+                                // q_j (stat_cls<1>)
+                                double rq = 0.0;
+                                if (k >= 1) {
+                                    if (k < Nl) {
+                                        double s_ = 0.0;
+#pragma unroll
+                                        for (int i = 0; i < NTASK; i++) s_ += rec[O_GQ + i * 6 + j] * rec[O_Y + i];
+                                        rq = P.dt * s_ + v[r][3];
+                                    }
+                                    rq -= v[r][5];
+                                }
+                                bound(6 + j, qj, v[r][11], v[r][12], v[r][13], v[r][14], rq);
+                                // v_j (stat_cls<2>)
+                                double rv = 0.0;
+                                if (k >= 1) {
+                                    if (k < Nl) {
+                                        rv = P.dt * (rec[O_GV + j] * rec[O_Y + 4] + c2 * (vj - uj));
+                                        rv += P.a12[j] * v[r][3] + P.a22[j] * v[r][4];
+                                    }
+                                    rv -= v[r][6];
+                                }
+                                if (k == 0) { rq = 0.0; rv = 0.0; }    // x_0 is eliminated (lbx_0 = ubx_0)
+                                as_ = fmax(as_, fmax(fabs(ru), fmax(fabs(rq), fabs(rv))));
+                                if (k < Nl) a_e.at(lane) = fmax(a_e.at(lane), fmax(fabs(rec[O_BD + j]), fabs(rec[O_BD + 6 + j])));
+                                if (k == 0) ai_ = fmax(ai_, fmax(fabs(sm.xhat[j] - qj), fabs(sm.xhat[6 + j] - vj)));   // lbx_0 = ubx_0 = x_hat
+                                a_s.at(lane) = as_; a_i.at(lane) = ai_; a_c.at(lane) = ac_;
+                            }
+                        }
+                    });
+                }
+                ex.par([&](int lane) {
+                    ex.put_max(sm.red[0], lane, a_s.at(lane)); ex.put_max(sm.red[1], lane, a_e.at(lane));
+                    ex.put_max(sm.red[2], lane, a_i.at(lane)); ex.put_max(sm.red[3], lane, a_c.at(lane));
+                });
+                rs = fmax(rs, ex.get_max(sm.red[0]));
+                re = fmax(re, ex.get_max(sm.red[1]));
+                ri = fmax(ri, ex.get_max(sm.red[2]));
+                rc = fmax(rc, ex.get_max(sm.red[3]));
+            }
+            copies([&](int lane, auto nl) {
+                constexpr int NL = decltype(nl)::value;
                 copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
             });
         }
@@ -2366,7 +2581,7 @@ struct Engine {
         double cost = lin_cost;
         if (c.pb->solver_type == 1) {
             // SQP_RTI: one linearisation, one QP, full step
-            if (!lin_valid) cost = nlp_pass(0.0, false, false, nullptr);
+            if (!lin_valid) cost = NLP_PASS(0.0, false, false, nullptr);
             const int qs = ipm_solve(&it);
             qp_iter += it;
             sqp_iter = 1;
@@ -2374,7 +2589,7 @@ struct Engine {
             if (!ok) status = 4;  // ACADOS_QP_FAILURE, iterate untouched
             // residuals / cost are evaluated at the new iterate (acados get_residuals() for RTI,
             // get_cost()); this linearisation is reused by the next solve() call
-            cost = nlp_pass(1.0, ok, false, res4);
+            cost = NLP_PASS(1.0, ok, false, res4);
             lin_valid = true;
         } else {
             const double tol = ex.smem().P.tol, tol_eq = ex.smem().P.tol_eq, tol_in = ex.smem().P.tol_ineq, tol_co = ex.smem().P.tol_comp;
@@ -2383,7 +2598,7 @@ struct Engine {
             bool pending = false;  // a step (alpha) waits to be applied by the next nlp_pass
             for (sqp_iter = 0; sqp_iter < c.pb->max_iter; sqp_iter++) {
                 if (pending || !lin_valid || sqp_iter == 0) {
-                    cost = nlp_pass(alpha, pending, true, res4);
+                    cost = NLP_PASS(alpha, pending, true, res4);
                     pending = false;
                     lin_valid = true;
                 }
@@ -2395,7 +2610,7 @@ struct Engine {
                 alpha = c.pb->fixed_step ? 1.0 : line_search(sqp_iter);
                 pending = true;
             }
-            if (pending) { cost = nlp_pass(alpha, true, true, nullptr); lin_valid = true; }  // max-iter exit: residuals of the last check stay
+            if (pending) { cost = NLP_PASS(alpha, true, true, nullptr); lin_valid = true; }  // max-iter exit: residuals of the last check stay
         }
         lin_cost = cost;
         *sqp_iter_out = sqp_iter;
