@@ -48,11 +48,7 @@ constexpr int L1 = 98;
 // lane per stage (every lane touches the same column of a different stage): stride 62
 constexpr int L2N = 62;
 
-#ifdef MPCB_OLD_NLP_PASS
-#define NLP_PASS nlp_pass
-#else
 #define NLP_PASS nlp_direct
-#endif
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
 #define PROF_ADD(i, v) prof[i] += ex.clock() - v
@@ -332,139 +328,7 @@ struct Engine {
     // Jacobian per stage (lane <-> stage), dynamics defect, cost = sum_k dt/2 r'Wr (acados
     // get_cost(), simulator.py:221) -- and evaluates acados' ocp_nlp_res_compute inf-norms
     // [stat, eq, ineq, comp] with the NLP multipliers (RTI: the QP's; SQP: the blended ones).
-    MPC_PASS double nlp_pass(double alpha, bool do_update, bool sqp_mult, double *res4)
-    {
-        PROF_T0(t0);
-        Smem &sm = ex.smem();
-        const InstParams &P = sm.P;
-        const Robot &rb = sm.rb;
-        const int Nl = ex.uni(ex.smem().n_hor);
-        const int W5M = 60;  // NPI, NLAM, NT
-        // SQP_RTI carries no NLP multipliers of its own: without them the whole N = 100 horizon is one chunk
-        const int CH = sqp_mult ? chunk_len(L1 + W5M + L2N, 2 * (L1 + W5M)) : chunk_len(L1 + L2N, 2 * L1);
-        double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
-        for (int k0 = 0; k0 <= Nl; k0 += CH) {
-            const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
-            double *v1 = ex.pool();                       // rows lo..hi, L1
-            double *v5 = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, 60 (SQP only)
-            double *v2 = v5 + (sqp_mult ? (size_t)(CH + 2) * W5M : 0);  // rows k0..k1, L2N
-            copies([&](int lane, auto nl) {
-                constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, lo, hi, lane);
-                if (sqp_mult) copy_lanes<60, 0, W5, 60, true, NL>(v5, ex.smem().w.G5, lo, hi, lane);
-            });
-            if (do_update) {
-                ex.par([&](int lane) {
-                    const int rows = hi - lo + 1;
-                    // chunks run in increasing k: the lower halo row was already updated (and stored) by
-                    // the previous chunk, the upper one has not been touched yet
-                    for (int e = lane; e < rows * NW; e += NT) {
-                        const int s = e / NW, ci = e - s * NW;
-                        if (lo + s < k0) continue;
-                        double *r1 = v1 + (size_t)s * L1;
-                        if (ci < 12) r1[O_X + ci] += alpha * r1[O_QW + 6 + ci];
-                        else if (lo + s < Nl) r1[O_U + ci - 12] += alpha * r1[O_QW + ci - 12];
-                    }
-                    if (sqp_mult) {
-                        for (int e = lane; e < rows * 60; e += NT) {
-                            const int s = e / 60, ci = e - s * 60;
-                            if (lo + s < k0) continue;
-                            const double *r1 = v1 + (size_t)s * L1;
-                            double *r5 = v5 + (size_t)s * 60;
-                            // NPI | NLAM | NT  <-  blend towards QPI | QLAM | QT (contiguous in G1 from O_QPI)
-                            r5[ci] += alpha * (r1[O_QPI + ci] - r5[ci]);
-                        }
-                    }
-                });
-            }
-            ex.par([&](int lane) {
-                double csum = 0.0;
-                for (int k = k0 + lane; k <= k1; k += NT) {
-                    double *rec = v2 + (size_t)(k - k0) * L2N;
-                    if (k < Nl) {
-                        const double *r1 = v1 + (size_t)(k - lo) * L1, *rn = r1 + L1;
-                        double xx[12], uu[6];
-#pragma unroll
-                        for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
-#pragma unroll
-                        for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i];
-                        task_lin<true>(rb, P, xx, xx + 6, rec);
-                        double s = 0.0;
-#pragma unroll
-                        for (int i = 0; i < NTASK; i++) {
-                            const double r = rec[O_R + i];
-                            s += P.w_task[i] * r * r;
-                            rec[O_Y + i] = P.w_task[i] * r;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 6; j++) {
-                            const double uj = uu[j], vj = xx[6 + j];
-                            const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
-                            s += 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
-                            rec[O_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - rn[O_X + j];
-                            rec[O_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - rn[O_X + 6 + j];
-                        }
-                        csum += 0.5 * P.dt * s;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
-                    }
-                }
-                ex.put_sum(sm.red[4], lane, csum);
-            });
-            cost += ex.get_sum(sm.red[4]);
-            if (res4) {
-                ex.par([&](int lane) {
-                    double a_s = 0, a_e = 0, a_i = 0, a_c = 0;
-                    const int rows = k1 - k0 + 1;
-                    for (int e = lane; e < rows * NW; e += NT) {
-                        const int s = e / NW, ci = e - s * NW, k = k0 + s;
-                        const double *pi_k = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NPI : v1 + (size_t)(k - lo) * L1 + O_QPI;
-                        const double *pi_m = sqp_mult ? v5 + (size_t)(imax(k - 1, lo) - lo) * 60 + O_NPI
-                                                      : v1 + (size_t)(imax(k - 1, lo) - lo) * L1 + O_QPI;
-                        const double *lam = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NLAM : v1 + (size_t)(k - lo) * L1 + O_QLAM;
-                        const double *tt = sqp_mult ? v5 + (size_t)(k - lo) * 60 + O_NT : v1 + (size_t)(k - lo) * L1 + O_QT;
-                        double v = stat_elem(k, ci, v1 + (size_t)(k - lo) * L1, v2 + (size_t)s * L2N, false, pi_k, pi_m);
-                        if (ci < NB && has_comp(Nl, k, ci)) {
-                            const double cur = v1[(size_t)(k - lo) * L1 + (ci < 6 ? O_U + ci : O_X + ci - 6)];
-                            if (bnd_lo(P, ci) > -BOUND_INF) {
-                                v -= lam[ci];
-                                a_i = fmax(a_i, fabs((bnd_lo(P, ci) - cur) + tt[ci]));
-                                a_c = fmax(a_c, fabs(lam[ci] * tt[ci]));
-                            }
-                            if (bnd_hi(P, ci) < BOUND_INF) {
-                                v += lam[12 + ci];
-                                a_i = fmax(a_i, fabs((cur - bnd_hi(P, ci)) + tt[12 + ci]));
-                                a_c = fmax(a_c, fabs(lam[12 + ci] * tt[12 + ci]));
-                            }
-                        }
-                        if (ci >= 6 && k == 0) v = 0.0;
-                        a_s = fmax(a_s, fabs(v));
-                        if (ci < NX && k < Nl) a_e = fmax(a_e, fabs(v2[(size_t)s * L2N + O_BD + ci]));
-                    }
-                    if (k0 == 0 && lane < NX) a_i = fmax(a_i, fabs(sm.xhat[lane] - v1[O_X + lane]));  // lbx_0 = ubx_0 = x_hat
-                    ex.put_max(sm.red[0], lane, a_s); ex.put_max(sm.red[1], lane, a_e); ex.put_max(sm.red[2], lane, a_i); ex.put_max(sm.red[3], lane, a_c);
-                });
-                rs = fmax(rs, ex.get_max(sm.red[0]));
-                re = fmax(re, ex.get_max(sm.red[1]));
-                ri = fmax(ri, ex.get_max(sm.red[2]));
-                rc = fmax(rc, ex.get_max(sm.red[3]));
-            }
-            copies([&](int lane, auto nl) {
-                constexpr int NL = decltype(nl)::value;
-                if (do_update) {
-                    copy_lanes<18, 0, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1, ex.smem().w.G1, k0, k1, lane);
-                    if (sqp_mult) copy_lanes<60, 0, W5, 60, false, NL>(v5 + (size_t)(k0 - lo) * 60, ex.smem().w.G5, k0, k1, lane);
-                }
-                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
-            });
-        }
-        if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
-        PROF_ADD(PF_NLP, t0);
-        return cost;
-    }
-
-    // The same pass, item-parallel (replaces nlp_pass; any horizon): the iterate is updated IN PLACE in HBM by 16-byte items, every
+    // Item-parallel (any horizon): the iterate is updated IN PLACE in HBM by 16-byte items, every
     // lane linearises one stage from operands it loads itself, and the residual norms are joint items (u_j, q_j, v_j together) --
     // no staging of the 96-column iterate record through LDS (81 KB per pass at N = 100), no copy-back.  The linearisation records
     // (60 doubles per stage) collect in LDS and leave with one coalesced store.
@@ -674,255 +538,12 @@ struct Engine {
         return cost;
     }
 
-    // Stationarity element (k,c) of the Lagrangian: cost gradient (+ GN Hessian * delta when
-    // `with_delta`, through y), dynamics adjoints; bound multipliers are added by the caller.
-    // r1 = G1 record of stage k, r2 = G2 record of stage k (y must be current).
-    MPC_HD double stat_elem(int k, int cidx, const double *r1, const double *r2, bool with_delta, const double *pk,
-                            const double *pm) const
-    {
-        if (cidx < 6) return stat_cls<0>(k, cidx, r1, r2, with_delta, pk, pm);
-        if (cidx < 12) return stat_cls<1>(k, cidx - 6, r1, r2, with_delta, pk, pm);
-        return stat_cls<2>(k, cidx - 12, r1, r2, with_delta, pk, pm);
-    }
-    // CLS 0: input u_j, 1: joint position q_j, 2: joint velocity v_j  (component cidx = 6 CLS + j)
-    template <int CLS>
-    MPC_HD double stat_cls(int k, int j, const double *r1, const double *r2, bool with_delta, const double *pk,
-                           const double *pm) const
-    {
-        const InstParams &P = ex.smem().P;
-        const int N = ex.smem().n_hor;   // (shadows the member: that one lives in scratch memory inside a pass)
-        double val = 0.0;
-        if (CLS == 0) {
-            if (k >= N) return 0.0;
-            double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
-            if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
-            const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
-            val = P.dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
-            val += P.b1[j] * pk[j] + P.b2[j] * pk[6 + j];
-            if (with_delta) val += P.dt * P.lm * r1[O_QW + j];   // levenberg_marquardt: dt*lm*I on the stage Hessian
-        } else if (CLS == 1) {
-            if (k == 0) return 0.0;
-            if (k < N) {
-                double s = 0.0;
-#pragma unroll
-                for (int i = 0; i < NTASK; i++) s += r2[O_GQ + i * 6 + j] * r2[O_Y + i];
-                val = P.dt * s + pk[j];
-            }
-            if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 6 + j];   // terminal stage: lm*I
-            val -= pm[j];
-        } else {
-            if (k == 0) return 0.0;
-            if (k < N) {
-                double uj = r1[O_U + j], vj = r1[O_X + 6 + j];
-                if (with_delta) { uj += r1[O_QW + j]; vj += r1[O_QW + 12 + j]; }
-                const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
-                val = P.dt * (r2[O_GV + j] * r2[O_Y + 4] + c2 * (vj - uj));
-                val += P.a12[j] * pk[j] + P.a22[j] * pk[6 + j];
-            }
-            if (with_delta) val += (k < N ? P.dt : 1.0) * P.lm * r1[O_QW + 12 + j];
-            val -= pm[6 + j];
-        }
-        return val;
-    }
-
-    // =========================================================================== IPM: residual pass
-    // MODE 0 (init, HPIPM warm_start = 2): keep (w, pi, lam, t) of the previous QP, clamp
-    // lam, t >= 0.1, embed x0.  MODE 1: apply the Newton step with length `a` (HPIPM
-    // update_var).  Then QP residuals, Gamma and the condensed gradient gt of the Newton system
-    // (HPIPM compute_Gamma_gamma).  out: nrm = [g, b, d, m], smu = sum(lam*t), nc = #bound sides.
-    // Results (inf-norms of the four residuals, sum of complementarity products, number of
-    // constraints in mode 0) are left in sm.ret[0..5]: handing them back through pointers into the
-    // caller's frame costs scratch-memory round trips.
-    MPC_PASS void residual_pass(int mode, double a)
-    {
-        PROF_T0(t0);
-        Smem &sm = ex.smem();
-        const InstParams &P = sm.P;
-        const int Nl = ex.uni(ex.smem().n_hor);
-        constexpr int W3D = 78, W3R = 66, WG = 42;
-        const int per = L1 + W3D + W2_LIN + W3R + WG;
-        const int CH = chunk_len(per, 2 * (L1 + W3D));
-        double ng = 0, nb = 0, nd = 0, nm = 0, smu = 0, nc = 0;
-        for (int k0 = 0; k0 <= Nl; k0 += CH) {
-            const int k1 = imin(k0 + CH - 1, Nl), lo = imax(k0 - 1, 0), hi = imin(k1 + 1, Nl);
-            double *v1 = ex.pool();                        // rows lo..hi, L1
-            double *v3d = v1 + (size_t)(CH + 2) * L1;   // rows lo..hi, DW|DPI|DLAM|DT
-            double *v2 = v3d + (size_t)(CH + 2) * W3D;  // rows k0..k1, compact [R..GV] (60)
-            double *v3r = v2 + (size_t)CH * W2_LIN;     // rows k0..k1, RG|RD|RM
-            double *vg = v3r + (size_t)CH * W3R;        // rows k0..k1, Gamma(12) | gt(18) | rb(12)
-            copies([&](int lane, auto nl) {
-                constexpr int NL = decltype(nl)::value;
-                copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, lo, hi, lane);
-                if (mode == 1) copy_lanes<W3D, O_DW, W3, W3D, true, NL>(v3d, ex.smem().w.G3, lo, hi, lane);
-                copy_lanes<W2_LIN, 0, W2, W2_LIN, true, NL>(v2, ex.smem().w.G2, k0, k1, lane);
-            });
-            PROF_T0(tx);
-            ex.par([&](int lane) {
-                const int rows = hi - lo + 1;
-                double ncl = 0.0;
-                if (mode == 1) {
-                    // (lower halo row: already updated and stored by the previous chunk)
-                    for (int e = lane; e < rows * NW; e += NT) {
-                        const int s = e / NW, ci = e - s * NW;
-                        if (lo + s >= k0) v1[(size_t)s * L1 + O_QW + ci] += a * v3d[(size_t)s * W3D + ci];
-                    }
-                    for (int e = lane; e < (rows - 1) * NX; e += NT) {  // pi_k += a * dpi stored at stage k+1
-                        const int s = e / NX, i = e - s * NX;
-                        if (lo + s >= k0 && lo + s < Nl) v1[(size_t)s * L1 + O_QPI + i] += a * v3d[(size_t)(s + 1) * W3D + 18 + i];
-                    }
-                }
-                for (int e = lane; e < rows * NB; e += NT) {
-                    const int s = e / NB, j = e - s * NB, k = lo + s;
-                    if (k < k0 || k > k1) continue;  // multipliers are only needed on own rows
-                    const bool hc = has_comp(Nl, k, j);
-                    const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
-                    double *lam = v1 + (size_t)s * L1 + O_QLAM, *t = v1 + (size_t)s * L1 + O_QT;
-                    const double *dl = v3d + (size_t)s * W3D + 30, *dt = v3d + (size_t)s * W3D + 54;
-                    if (mode == 0) {
-                        lam[j] = ipm::warm_lam(blo, lam[j]); t[j] = ipm::warm_t(blo, t[j]);
-                        lam[12 + j] = ipm::warm_lam(bhi, lam[12 + j]); t[12 + j] = ipm::warm_t(bhi, t[12 + j]);
-                        ncl += (blo ? 1.0 : 0.0) + (bhi ? 1.0 : 0.0);
-                    } else {
-                        // all loads first (see corrector_bwd_pass)
-                        const double l0 = lam[j], t0_ = t[j], l1 = lam[12 + j], t1_ = t[12 + j];
-                        const double d0 = dl[j], e0 = dt[j], d1 = dl[12 + j], e1 = dt[12 + j];
-                        lam[j] = ipm::step_floor(blo, l0, a, d0); t[j] = ipm::step_floor(blo, t0_, a, e0);
-                        lam[12 + j] = ipm::step_floor(bhi, l1, a, d1); t[12 + j] = ipm::step_floor(bhi, t1_, a, e1);
-                    }
-                }
-                if (mode == 0) {
-                    if (lo == 0 && lane < NX) v1[O_QW + 6 + lane] = sm.xhat[lane] - v1[O_X + lane];
-                    if (hi == Nl && lane < NU) v1[(size_t)(Nl - lo) * L1 + O_QW + lane] = 0.0;
-                }
-                ex.put_sum(sm.red[5], lane, ncl);
-            });
-            if (mode == 0) nc += ex.get_sum(sm.red[5]);
-            PROF_ADD(PF_X1, tx);
-            PROF_T0(ty);
-            // y_ki = w_i (r_ki + G_ki . delta_k): weighted linearised task residual
-            ex.par([&](int lane) {
-                const int rows = k1 - k0 + 1;
-                for (int e = lane; e < rows * NTASK; e += NT) {
-                    const int s = e / NTASK, i = e - s * NTASK, k = k0 + s;
-                    double *r2 = v2 + (size_t)s * W2_LIN;
-                    if (k >= Nl) continue;
-                    const double *dw = v1 + (size_t)(k - lo) * L1 + O_QW;
-                    double v = r2[O_R + i];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) v += r2[O_GQ + i * 6 + j] * dw[6 + j];
-                    if (i == 4) {
-#pragma unroll
-                        for (int j = 0; j < 6; j++) v += r2[O_GV + j] * dw[12 + j];
-                    }
-                    r2[O_Y + i] = P.w_task[i] * v;
-                }
-            });
-            PROF_ADD(PF_X2, ty);
-            PROF_T0(tz);
-            // residuals, Gamma, gt.  Outputs: v3r (RG|RD|RM) and vg.  Four kinds of rows -- u, q, v
-            // components of the stationarity residual and the dynamics residual -- each have their own
-            // formulas: a wavefront works on ONE kind at a time, so no lane diverges from its neighbours.
-            ex.par([&](int lane) {
-                double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
-                const int rows = k1 - k0 + 1;
-                constexpr int NWVc = NT / WAVE, NR = 4;
-                constexpr int PARTS = NWVc >= NR ? NWVc / NR : 1, RSTEP = NWVc >= NR ? NR : NWVc;
-                const int w = ex.uni(lane >> 6), l6 = lane & (WAVE - 1);
-                const int part = NWVc >= NR ? w / NR : 0;
-                auto stat_rows = [&](auto cls) {
-                    constexpr int CLS = decltype(cls)::value;
-                    for (int e = l6 + WAVE * part; e < rows * 6; e += WAVE * PARTS) {
-                        const int s = e / 6, j = e - s * 6, ci = CLS * 6 + j, k = k0 + s;
-                        const double *r1 = v1 + (size_t)(k - lo) * L1;
-                        const double *r2 = v2 + (size_t)s * W2_LIN;
-                        const double *pk = r1 + O_QPI, *pm = v1 + (size_t)(imax(k - 1, lo) - lo) * L1 + O_QPI;
-                        double *o3 = v3r + (size_t)s * W3R, *og = vg + (size_t)s * 42;
-                        double rg = stat_cls<CLS>(k, j, r1, r2, true, pk, pm);
-                        double gt = rg;
-                        if (CLS < 2) {
-                            const bool hc = has_comp(Nl, k, ci);
-                            const bool blo = hc && bnd_lo(P, ci) > -BOUND_INF, bhi = hc && bnd_hi(P, ci) < BOUND_INF;
-                            const double v_ = r1[CLS == 0 ? O_U + j : O_X + j], v = hc ? v_ : 0.0, dv = r1[O_QW + ci];
-                            double gam = 0.0, rdl = 0, rml = 0, rdu = 0, rmu = 0;
-                            // all loads first, decisions on registers only (see corrector_bwd_pass)
-                            const double l_lo = r1[O_QLAM + ci], t_lo = r1[O_QT + ci], l_hi = r1[O_QLAM + 12 + ci], t_hi = r1[O_QT + 12 + ci];
-                            const double b_lo = bnd_lo(P, ci), b_hi = bnd_hi(P, ci);
-                            if (blo) {
-                                const double l = l_lo, t = t_lo, it = fast_rcp(t);
-                                rdl = dv - (b_lo - v) - t;
-                                rml = l * t;
-                                rg -= l; gt -= l;
-                                gam += l * it;
-                                gt += (rml + l * rdl) * it;
-                                a_mu += rml;
-                                a_d = fmax(a_d, fabs(rdl)); a_m = fmax(a_m, fabs(rml));
-                            }
-                            if (bhi) {
-                                const double l = l_hi, t = t_hi, it = fast_rcp(t);
-                                rdu = (b_hi - v) - dv - t;
-                                rmu = l * t;
-                                rg += l; gt += l;
-                                gam += l * it;
-                                gt -= (rmu + l * rdu) * it;
-                                a_mu += rmu;
-                                a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
-                            }
-                            o3[O_RD + ci] = rdl; o3[O_RD + 12 + ci] = rdu;
-                            o3[O_RM + ci] = rml; o3[O_RM + 12 + ci] = rmu;
-                            og[ci] = gam;
-                        }
-                        o3[O_RG + ci] = rg;
-                        og[12 + ci] = gt;
-                        a_g = fmax(a_g, fabs(rg));
-                    }
-                };
-                for (int role = NWVc >= NR ? w % NR : w; role < NR; role += RSTEP) {
-                    if (role == 0) stat_rows(std::integral_constant<int, 0>{});
-                    else if (role == 1) stat_rows(std::integral_constant<int, 1>{});
-                    else if (role == 2) stat_rows(std::integral_constant<int, 2>{});
-                    else {
-                        for (int e = l6 + WAVE * part; e < rows * NX; e += WAVE * PARTS) {
-                            const int s = e / NX, i = e - s * NX, k = k0 + s;
-                            double v = 0.0;
-                            if (k < Nl) {
-                                const double *dw = v1 + (size_t)(k - lo) * L1 + O_QW, *dn = dw + L1;
-                                if (i < 6) v = dw[6 + i] + P.a12[i] * dw[12 + i] + P.b1[i] * dw[i];
-                                else v = P.a22[i - 6] * dw[6 + i] + P.b2[i - 6] * dw[i - 6];
-                                v += v2[(size_t)s * W2_LIN + O_BD + i] - dn[6 + i];
-                                a_b = fmax(a_b, fabs(v));
-                            }
-                            vg[(size_t)s * WG + 30 + i] = v;
-                        }
-                    }
-                }
-                ex.put_max(sm.red[0], lane, a_g); ex.put_max(sm.red[1], lane, a_b); ex.put_max(sm.red[2], lane, a_d); ex.put_max(sm.red[3], lane, a_m);
-                ex.put_sum(sm.red[4], lane, a_mu);
-            });
-            ng = fmax(ng, ex.get_max(sm.red[0]));
-            nb = fmax(nb, ex.get_max(sm.red[1]));
-            nd = fmax(nd, ex.get_max(sm.red[2]));
-            nm = fmax(nm, ex.get_max(sm.red[3]));
-            smu += ex.get_sum(sm.red[4]);
-            PROF_ADD(PF_X3, tz);
-            copies([&](int lane, auto nl) {
-                constexpr int NL = decltype(nl)::value;
-                copy_lanes<78, O_QW, W1, L1, false, NL>(v1 + (size_t)(k0 - lo) * L1 + O_QW, ex.smem().w.G1, k0, k1, lane);
-                copy_lanes<10, 0, W2, W2_LIN, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);        // r (unchanged) and y
-                copy_lanes<WG, O_GAM, W2, WG, false, NL>(vg, ex.smem().w.G2, k0, k1, lane);        // Gamma | gt | rb
-                copy_lanes<W3R, 0, W3, W3R, false, NL>(v3r, ex.smem().w.G3, k0, k1, lane);         // RG | RD | RM
-            });
-        }
-        ex.par([&](int lane) {
-            if ((lane & (WAVE - 1)) == 0) {
-                sm.ret[0] = ng; sm.ret[1] = nb; sm.ret[2] = nd; sm.ret[3] = nm; sm.ret[4] = smu;
-                if (mode == 0) sm.ret[5] = nc;
-            }
-        });
-        PROF_ADD(PF_RES, t0);
-    }
-
     // =========================================================================== IPM: residual pass, item-parallel
-    // Same algebra as residual_pass (which it replaces), no LDS staging and no chunks: every lane works on ITEMS whose
+    // MODE 0 (init, HPIPM warm_start = 2): keep (w, pi, lam, t) of the previous QP, clamp lam, t >= 0.1, embed x0.  MODE 1: apply the
+    // Newton step with length `a` (HPIPM update_var).  Then the QP residuals, Gamma and the condensed gradient gt of the Newton system
+    // (HPIPM compute_Gamma_gamma).  Results -- inf-norms of the four residuals [g, b, d, m], sum of the complementarity products,
+    // number of bound sides in mode 0 -- are left in sm.ret[0..5] (handing them back through pointers costs scratch round trips).
+    // No LDS staging and no chunks: every lane works on ITEMS whose
     // operands it loads straight from HBM (8- and 16-byte loads, coalesced in runs of 6..12 doubles), all loads of a
     // batch of items in flight before the first is used.
     //   U  elementwise update of (dw, pi, lam, t) -- every element is read and written by exactly one item;
@@ -2391,11 +2012,7 @@ struct Engine {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
         const bool res = resident_ok();   // the horizon's factor fits the LDS pool: resident sweeps
-#ifdef MPCB_OLD_RESIDUAL
-        residual_pass(0, 0.0);
-#else
         residual_direct(0, 0.0);
-#endif
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         int it = 0, status = 1;
@@ -2433,11 +2050,7 @@ struct Engine {
                 alpha = a_aff;
             }
             const double a = ipm::step_scale(alpha);
-#ifdef MPCB_OLD_RESIDUAL
-            residual_pass(1, a);
-#else
             residual_direct(1, a);
-#endif
             mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         }
 #ifdef MPCB_PROFILE
