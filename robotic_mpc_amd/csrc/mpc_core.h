@@ -308,6 +308,35 @@ struct Engine {
         m.L = (Nl + RS_GROUPS - 1) / RS_GROUPS;
         return m;
     }
+    // SEGMENT map: the same arrays sized for one segment of SEG_T transitions (+ its end state), chunk length SEG_L
+    MPC_HD ResMap seg_map() const
+    {
+        const int pool_n = ex.uni(ex.smem().pool_n);
+        constexpr int NSS = SEG_T + 1;
+        const int persist = NSS * RS_PER_STAGE + RS_GROUPS * 144;
+        ResMap m;
+        m.scr = ex.pool();
+        m.scr_n = pool_n - persist;
+        m.K = ex.pool() + m.scr_n;
+        m.VH = m.K + (size_t)NSS * 72;
+        m.E = m.VH + (size_t)NSS * 6;
+        m.P = m.E + (size_t)NSS * 12;
+        m.PHI = m.P + (size_t)NSS * 12;
+        m.L = SEG_L;
+        return m;
+    }
+    // horizons beyond the resident limit, with a whole CU's pool: segment-wise residency (the factor goes through HBM, the sweeps
+    // load it back one segment at a time and run chunk-parallel inside the segment)
+    MPC_HD bool segment_ok() const
+    {
+#ifdef MPCB_NO_RESIDENT
+        return false;
+#else
+        const int pool_n = ex.uni(ex.smem().pool_n);
+        const int scr = pool_n - ((SEG_T + 1) * RS_PER_STAGE + RS_GROUPS * 144);
+        return ex.uni(RS_GROUPS == 16 && !resident_ok() && scr >= (SEG_T + 1) * 30 + 2 * RS_GROUPS * 12 + 64);
+#endif
+    }
     MPC_HD bool resident_ok() const
     {
 #ifdef MPCB_NO_RESIDENT
@@ -856,9 +885,12 @@ struct Engine {
 
     // RES: the factor stays in LDS (see above): K, R~^-1 h_u, e, p go to the resident arrays, the chunk record and the
     // HBM store shrink to [P | w | R~^-1] (126 of 228 columns), and the first background wavefront accumulates Phi_c.
-    template <bool RES>
+    // MODE 0: plain (everything through HBM, streaming sweeps follow); 1: RES; 2: SEG -- the plain factor record in HBM plus the
+    // chunk transition matrices (chunks of SEG_L transitions) for the segment-resident sweeps.
+    template <int MODE>
     MPC_PASS void fact_pass_t()
     {
+        constexpr bool RES = MODE == 1, SEG = MODE == 2;
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
@@ -1158,15 +1190,15 @@ struct Engine {
                 // the first stage of chunk ci
                 ex.await(&sm.prog1, Nl - k1);
                 if ((lane & (WAVE - 1)) == 0) ex.post_add(&sm.flg[1], 1);
-                if constexpr (RES) {
+                if constexpr (RES || SEG) {
                     // copies issued: the first background wavefront follows the recursion and accumulates the chunk
                     // transition matrix Phi_c <- Phi_c Acl_k (lane i < 12 holds row i in registers), k descending
 #ifndef MPCB_DIAG_NO_PHI
                     if (lane < WAVE) {
-                        const int L = rm.L;
+                        const int L = SEG ? SEG_L : rm.L;
                         for (int k = imin(k1, Nl - 1); k >= k0; k--) {
                             ex.await(&sm.prog, Nl - k);
-                            const double *kk = rm.K + (size_t)k * 72;
+                            const double *kk = RES ? rm.K + (size_t)k * 72 : vf_of(ci) + (size_t)(k - k0) * WF - FO + O_K;
                             const int c = k / L;
                             const bool first = ex.uni(k == imin((c + 1) * L, Nl) - 1), last = ex.uni(k == c * L);
                             // K_k is the same for every lane: ONE 16-byte LDS read per lane (lanes 0..35 cover the 72 entries),
@@ -1190,8 +1222,13 @@ struct Engine {
 #pragma unroll
                                 for (int j = 0; j < 12; j++) phi[j].at(lane) = nw[j];
                                 if (last && lane < NX) {
+                                    if (SEG) {
 #pragma unroll
-                                    for (int j = 0; j < 12; j++) rm.PHI[(size_t)c * 144 + lane * 12 + j] = nw[j];
+                                        for (int j = 0; j < 12; j++) gst(ex.smem().w.PH + (size_t)c * 144 + lane * 12 + j, nw[j]);
+                                    } else {
+#pragma unroll
+                                        for (int j = 0; j < 12; j++) rm.PHI[(size_t)c * 144 + lane * 12 + j] = nw[j];
+                                    }
                                 }
                             }
                         }
@@ -1614,12 +1651,14 @@ struct Engine {
     //   BWD:  p_k = c_k + Acl_k' p_{k+1},   p_N = c_N (vec holds c on entry) -> vec[k] = p_k, in place
     // with Acl_k = A - B K_k.  `xch`, `xs`: [RS_GROUPS][12] hand-over slots / chunk boundary values (scratch).
     // Ends with every lane's LDS writes issued, NOT with a barrier.
+    // All indices are LOCAL to the range the maps describe (the whole horizon, or one segment): `nt` transitions, states 0..nt;
+    // `x0`: FWD boundary value at state 0 (nullptr: zero).
     template <bool FWD>
-    MPC_HD void rs_recursion(const ResMap &rm, double *vec, double *xch, double *xs)
+    MPC_HD void rs_recursion(const ResMap &rm, double *vec, double *xch, double *xs, int nt, const double *x0 = nullptr)
     {
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(ex.smem().n_hor), L = rm.L;
+        const int Nl = ex.uni(nt), L = rm.L;
         const int Jused = (Nl + L - 1) / L;
         typename Ex::template PerLane<double> z;
         typename Ex::template PerLane<D2> ab, bb;
@@ -1710,7 +1749,7 @@ struct Engine {
             typename Ex::template PerLane<double> xr;
             int cur = 0;
             ex.seq([&](int lane) {
-                const double v = (!FWD && lane < NX) ? vec[(size_t)Nl * 12 + lane] : 0.0;
+                const double v = lane < NX ? (FWD ? (x0 ? x0[lane] : 0.0) : vec[(size_t)Nl * 12 + lane]) : 0.0;
                 xr.at(lane) = v;
                 if (lane < NX) ex.share(sm.pv[cur], lane, v);
             });
@@ -1745,127 +1784,149 @@ struct Engine {
     // Forward sweep on the resident factor: dx by rs_recursion, then item-parallel (lane <-> (stage, bounded component)):
     // du = -(R~^-1 h_u + K dx), dt, dlam (HPIPM compute_lam_t), largest feasible step, centering sums; the final sweep
     // also dpi_{k-1} = p_k + P_k dx_k and the whole Newton step to HBM.  Leaves alpha, S0, S1, S2 in sm.cen[0..3].
-    template <bool AFFINE>
+    // SEG: the factor of ONE SEGMENT of SEG_T transitions at a time (loaded from the HBM record the plain factorisation wrote),
+    // segments in ascending order, dx handed from segment to segment; all LDS indices are local to the segment (kb = its first stage).
+    template <bool AFFINE, bool SEG>
     MPC_PASS double fwd_resident()
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
-        const ResMap rm = res_map();
-        double *X = rm.scr, *xch = X + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
-        const int items = NS * 6;      // joint items (k, j): the bounded components u_j and q_j together
-        const int items_pi = NS * NB;  // dpi items (k, state component)
+        const int Nl = ex.uni(ex.smem().n_hor);
+        const ResMap rm = SEG ? seg_map() : res_map();
+        const int NSL = SEG ? SEG_T + 1 : Nl + 1;       // states the maps hold
+        double *X = rm.scr, *xch = X + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *xin = xs + RS_GROUPS * 12;
         constexpr int R = rounds_for(6);
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
         typename Ex::template PerLane<double> ld[R][16];
         typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
-        // operands of a batch of items: lam, t (G1), rd, rm (G3); lower | upper of u_j, then of q_j -- unconditional, clamped
-        auto issue = [&](int base) {
-            ex.wpar([&](int lane) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = imin(base + r * NT + lane, items - 1), k = e / 6, j = e - k * 6;
-                    const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int c = j + 6 * h;
-                        ld[r][8 * h + 0].at(lane) = gld(g1 + O_QLAM + c); ld[r][8 * h + 1].at(lane) = gld(g1 + O_QLAM + 12 + c);
-                        ld[r][8 * h + 2].at(lane) = gld(g1 + O_QT + c);   ld[r][8 * h + 3].at(lane) = gld(g1 + O_QT + 12 + c);
-                        ld[r][8 * h + 4].at(lane) = gld(g3 + O_RD + c);   ld[r][8 * h + 5].at(lane) = gld(g3 + O_RD + 12 + c);
-                        ld[r][8 * h + 6].at(lane) = gld(g3 + O_RM + c);   ld[r][8 * h + 7].at(lane) = gld(g3 + O_RM + 12 + c);
-                    }
-                }
-                if (base == 0) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; }
-            });
-        };
-        // final sweep: row j of the packed P_k for the dpi items, straight from HBM (issued with the other operands)
         constexpr int RP = AFFINE ? 1 : RS_ROUNDS;
         typename Ex::template PerLane<double> pmr[RP][12];
-        auto issue_pi = [&](int base) {
-            ex.wpar([&](int lane) {
+        ex.wpar([&](int lane) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; });
+        for (int kb = 0; kb == 0 || kb < Nl; kb += SEG ? SEG_T : Nl + 1) {
+            const int nt = ex.uni(SEG ? imin(SEG_T, Nl - kb) : Nl);          // transitions of this segment
+            const int nsi = nt + (kb + nt == Nl ? 1 : 0);                    // stages with items: the end state only in the last segment
+            const int items = nsi * 6;        // joint items (k, j): the bounded components u_j and q_j together
+            const int items_pi = nsi * NB;    // dpi items (k, state component)
+            // operands of a batch of items: lam, t (G1), rd, rm (G3); lower | upper of u_j, then of q_j -- unconditional, clamped
+            auto issue = [&](int base) {
+                ex.wpar([&](int lane) {
 #pragma unroll
-                for (int r = 0; r < RP; r++) {
-                    const int e = imin(base + r * NT + lane, items_pi - 1), k = e / NB, j = e - k * NB;
-                    const double *g4 = G4 + (size_t)k * W4 + O_PM;
-#pragma unroll
-                    for (int i = 0; i < NX; i++) pmr[r][i].at(lane) = gld(g4 + tri_sym(j, i));
-                }
-            });
-        };
-        issue(0);
-        if (!AFFINE) issue_pi(0);
-        PROF_T0(ts);
-        rs_recursion<true>(rm, X, xch, xs);
-        ex.barrier();
-        PROF_ADD(PF_SEQ_FWD, ts);
-        for (int base = 0; base < items; base += R * NT) {
-            if (base > 0) issue(base);
-            ex.wpar([&](int lane) {
-                double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
-                auto side = [&](bool on, double sdv, double l, double t, double rd, double rmv, double &dt_o, double &dl_o) {
-                    ipm::lam_t_side(on, sdv, l, t, rd, rmv, al, a0, a1, a2, dt_o, dl_o);   // (mpc_ipm.h: compute_lam_t, step length, centering sums)
-                };
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = base + r * NT + lane;
-                    if (e < items) {
-                        const int k = e / 6, j = e - k * 6;
-                        const double *dxk = X + (size_t)k * 12;
-                        double *g3 = G3 + (size_t)k * W3;
-                        // du_k[j] = -(R~^-1 h_u + K dx_k)[j]  (stage N has no input: 0)
-                        const int kc = imin(k, Nl - 1);
-                        const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)kc * 72 + j * 12);
-                        const D2 *x2 = reinterpret_cast<const D2 *>(dxk);
-                        double s0 = rm.VH[(size_t)kc * 6 + j], s1 = 0.0;
-#pragma unroll
-                        for (int i = 0; i < NX; i += 2) { const D2 kv = kr[i >> 1], xv = x2[i >> 1]; s0 += kv.x * xv.x; s1 += kv.y * xv.y; }
-                        const double du = k < Nl ? -(s0 + s1) : 0.0, dq = dxk[j];
-                        if (!AFFINE) {
-                            gst(g3 + O_DW + j, du); gst(g3 + O_DW + 6 + j, dq); gst(g3 + O_DW + 12 + j, dxk[6 + j]);   // du_k, dx_k
-                        }
-                        const bool oku = k < Nl, okq = k >= 1 && k < Nl;
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), kl = e / 6, j = e - kl * 6, k = kb + kl;
+                        const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             const int c = j + 6 * h;
-                            const bool ok = h == 0 ? oku : okq;
-                            const bool blo = ok && sm.bon[c] != 0.0, bhi = ok && sm.bon[12 + c] != 0.0;
-                            const double dv = h == 0 ? du : dq;
-                            double dtl, dll, dtu, dlu;
-                            side(blo, dv, ld[r][8 * h + 0].at(lane), ld[r][8 * h + 2].at(lane), ld[r][8 * h + 4].at(lane), ld[r][8 * h + 6].at(lane), dtl, dll);
-                            side(bhi, -dv, ld[r][8 * h + 1].at(lane), ld[r][8 * h + 3].at(lane), ld[r][8 * h + 5].at(lane), ld[r][8 * h + 7].at(lane), dtu, dlu);
-                            gst(g3 + O_DLAM + c, dll); gst(g3 + O_DLAM + 12 + c, dlu);
-                            gst(g3 + O_DT + c, dtl);   gst(g3 + O_DT + 12 + c, dtu);
+                            ld[r][8 * h + 0].at(lane) = gld(g1 + O_QLAM + c); ld[r][8 * h + 1].at(lane) = gld(g1 + O_QLAM + 12 + c);
+                            ld[r][8 * h + 2].at(lane) = gld(g1 + O_QT + c);   ld[r][8 * h + 3].at(lane) = gld(g1 + O_QT + 12 + c);
+                            ld[r][8 * h + 4].at(lane) = gld(g3 + O_RD + c);   ld[r][8 * h + 5].at(lane) = gld(g3 + O_RD + 12 + c);
+                            ld[r][8 * h + 6].at(lane) = gld(g3 + O_RM + c);   ld[r][8 * h + 7].at(lane) = gld(g3 + O_RM + 12 + c);
                         }
                     }
-                }
-                r_al.at(lane) = al; r_a0.at(lane) = a0; r_a1.at(lane) = a1; r_a2.at(lane) = a2;
-            });
-        }
-        if (!AFFINE) {
-            constexpr int R = RS_ROUNDS;
-            const int items = items_pi;
-            for (int base = 0; base < items; base += R * NT) {
-                // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1})
-                if (base > 0) issue_pi(base);
+                });
+            };
+            // final sweep: row j of the packed P_k for the dpi items, straight from HBM (issued with the other operands)
+            auto issue_pi = [&](int base) {
                 ex.wpar([&](int lane) {
+#pragma unroll
+                    for (int r = 0; r < RP; r++) {
+                        const int e = imin(base + r * NT + lane, items_pi - 1), kl = e / NB, j = e - kl * NB;
+                        const double *g4 = G4 + (size_t)(kb + kl) * W4 + O_PM;
+#pragma unroll
+                        for (int i = 0; i < NX; i++) pmr[r][i].at(lane) = gld(g4 + tri_sym(j, i));
+                    }
+                });
+            };
+            if (SEG) {
+                // this segment's factor and chunk transition matrices: HBM -> the resident arrays (coalesced bursts)
+                const int c0 = kb / SEG_L, nc = (nt + SEG_L - 1) / SEG_L;
+                copies([&](int lane, auto nl) {
+                    constexpr int NL = decltype(nl)::value;
+                    copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
+                    copy_lanes<6, O_VH, W4, 6, true, NL>(rm.VH, G4, kb, kb + nt - 1, lane);
+                    copy_lanes<12, O_E, W4, 12, true, NL>(rm.E, G4, kb, kb + nt - 1, lane);
+                    if (!AFFINE) copy_lanes<12, O_PV, W4, 12, true, NL>(rm.P, G4, kb, kb + nsi - 1, lane);
+                    copy_lanes<144, 0, 144, 144, true, NL>(rm.PHI, ex.smem().w.PH, c0, c0 + nc - 1, lane);
+                });
+            }
+            issue(0);
+            if (!AFFINE) issue_pi(0);
+            PROF_T0(ts);
+            rs_recursion<true>(rm, X, xch, xs, nt, kb > 0 ? xin : nullptr);
+            ex.barrier();
+            PROF_ADD(PF_SEQ_FWD, ts);
+            for (int base = 0; base < items; base += R * NT) {
+                if (base > 0) issue(base);
+                ex.wpar([&](int lane) {
+                    double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
+                    auto side = [&](bool on, double sdv, double l, double t, double rd, double rmv, double &dt_o, double &dl_o) {
+                        ipm::lam_t_side(on, sdv, l, t, rd, rmv, al, a0, a1, a2, dt_o, dl_o);   // (mpc_ipm.h: compute_lam_t, step length, centering sums)
+                    };
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int e = base + r * NT + lane;
                         if (e < items) {
-                            const int k = e / NB, j = e - k * NB;
-                            const double *dxk = X + (size_t)k * 12;
-                            double v = 0.0;
-                            if (k >= 1) {
-                                double s0 = rm.P[(size_t)k * 12 + j], s1 = 0.0;
+                            const int kl = e / 6, j = e - kl * 6, k = kb + kl;
+                            const double *dxk = X + (size_t)kl * 12;
+                            double *g3 = G3 + (size_t)k * W3;
+                            // du_k[j] = -(R~^-1 h_u + K dx_k)[j]  (stage N has no input: 0)
+                            const int kc = imin(kl, nt - 1);
+                            const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)kc * 72 + j * 12);
+                            const D2 *x2 = reinterpret_cast<const D2 *>(dxk);
+                            double s0 = rm.VH[(size_t)kc * 6 + j], s1 = 0.0;
 #pragma unroll
-                                for (int i = 0; i < NX; i += 2) { s0 += pmr[r][i].at(lane) * dxk[i]; s1 += pmr[r][i + 1].at(lane) * dxk[i + 1]; }
-                                v = s0 + s1;
+                            for (int i = 0; i < NX; i += 2) { const D2 kv = kr[i >> 1], xv = x2[i >> 1]; s0 += kv.x * xv.x; s1 += kv.y * xv.y; }
+                            const double du = k < Nl ? -(s0 + s1) : 0.0, dq = dxk[j];
+                            if (!AFFINE) {
+                                gst(g3 + O_DW + j, du); gst(g3 + O_DW + 6 + j, dq); gst(g3 + O_DW + 12 + j, dxk[6 + j]);   // du_k, dx_k
                             }
-                            gst(G3 + (size_t)k * W3 + O_DPI + j, v);
+                            const bool oku = k < Nl, okq = k >= 1 && k < Nl;
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const int c = j + 6 * h;
+                                const bool ok = h == 0 ? oku : okq;
+                                const bool blo = ok && sm.bon[c] != 0.0, bhi = ok && sm.bon[12 + c] != 0.0;
+                                const double dv = h == 0 ? du : dq;
+                                double dtl, dll, dtu, dlu;
+                                side(blo, dv, ld[r][8 * h + 0].at(lane), ld[r][8 * h + 2].at(lane), ld[r][8 * h + 4].at(lane), ld[r][8 * h + 6].at(lane), dtl, dll);
+                                side(bhi, -dv, ld[r][8 * h + 1].at(lane), ld[r][8 * h + 3].at(lane), ld[r][8 * h + 5].at(lane), ld[r][8 * h + 7].at(lane), dtu, dlu);
+                                gst(g3 + O_DLAM + c, dll); gst(g3 + O_DLAM + 12 + c, dlu);
+                                gst(g3 + O_DT + c, dtl);   gst(g3 + O_DT + 12 + c, dtu);
+                            }
                         }
                     }
+                    r_al.at(lane) = al; r_a0.at(lane) = a0; r_a1.at(lane) = a1; r_a2.at(lane) = a2;
                 });
+            }
+            if (!AFFINE) {
+                for (int base = 0; base < items_pi; base += RP * NT) {
+                    // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1})
+                    if (base > 0) issue_pi(base);
+                    ex.wpar([&](int lane) {
+#pragma unroll
+                        for (int r = 0; r < RP; r++) {
+                            const int e = base + r * NT + lane;
+                            if (e < items_pi) {
+                                const int kl = e / NB, j = e - kl * NB, k = kb + kl;
+                                const double *dxk = X + (size_t)kl * 12;
+                                double v = 0.0;
+                                if (k >= 1) {
+                                    double s0 = rm.P[(size_t)kl * 12 + j], s1 = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < NX; i += 2) { s0 += pmr[r][i].at(lane) * dxk[i]; s1 += pmr[r][i + 1].at(lane) * dxk[i + 1]; }
+                                    v = s0 + s1;
+                                }
+                                gst(G3 + (size_t)k * W3 + O_DPI + j, v);
+                            }
+                        }
+                    });
+                }
+            }
+            if (SEG) {
+                // dx at the segment's end state is the next segment's boundary value (the arrays are about to be reloaded)
+                ex.wpar([&](int lane) { if (lane < NX) xin[lane] = X[(size_t)nt * 12 + lane]; });
+                ex.barrier();
             }
         }
         ex.par([&](int lane) {
@@ -1884,123 +1945,153 @@ struct Engine {
     // Centering corrector + backward solve on the resident factor (see corrector_bwd_pass for the algebra):
     //   items (stage, component): rm, rebuilt gt -> LDS ; c_k -> resident p array ; rs_recursion (p in place) ;
     //   items: h_u, R~^-1 h_u, e -> resident.  Only rm goes back to HBM.
+    // SEG: segment by segment from the top of the horizon, p handed down; K comes from HBM, R~^-1 h_u | e | p go back there.
+    template <bool SEG>
     MPC_PASS void corr_resident(double sigma_mu)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
-        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
-        const ResMap rm = res_map();
-        double *GT = rm.scr, *RW = GT + (size_t)NS * 18, *xch = RW + (size_t)NS * 12, *xs = xch + RS_GROUPS * 12;
-        const int items = NS * NB;
+        const int Nl = ex.uni(ex.smem().n_hor);
+        const ResMap rm = SEG ? seg_map() : res_map();
+        const int NSL = SEG ? SEG_T + 1 : Nl + 1;
+        double *GT = rm.scr, *RW = GT + (size_t)NSL * 18, *xch = RW + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *pin = xs + RS_GROUPS * 12;
         constexpr int R = RS_ROUNDS;
         double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
-        // ---- rm, gt of every bounded component (+ w_k into LDS); gt of the velocity components is rg
-        for (int base = 0; base < items; base += R * NT) {
-            ex.wpar([&](int lane) {
-                double v[R][12];
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = imin(base + r * NT + lane, items - 1), k = e / NB, j = e - k * NB;
-                    const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
-                    v[r][0] = gld(g1 + O_QLAM + j); v[r][1] = gld(g1 + O_QLAM + 12 + j);
-                    v[r][2] = gld(g1 + O_QT + j);   v[r][3] = gld(g1 + O_QT + 12 + j);
-                    v[r][4] = gld(g3 + O_DLAM + j); v[r][5] = gld(g3 + O_DLAM + 12 + j);
-                    v[r][6] = gld(g3 + O_DT + j);   v[r][7] = gld(g3 + O_DT + 12 + j);
-                    v[r][8] = gld(g3 + O_RD + j);   v[r][9] = gld(g3 + O_RD + 12 + j);
-                    v[r][10] = gld(g3 + O_RG + j);
-                    v[r][11] = gld(G4 + (size_t)k * W4 + O_WV + j);
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = base + r * NT + lane;
-                    if (e < items) {
-                        const int k = e / NB, j = e - k * NB;
-                        const bool hc = j < 6 ? k < Nl : (k >= 1 && k < Nl);
-                        const bool blo = hc && sm.bon[j] != 0.0, bhi = hc && sm.bon[12 + j] != 0.0;
-                        const double ll = v[r][0], lu = v[r][1], tl = v[r][2], tu = v[r][3];
-                        const double dll = v[r][4], dlu = v[r][5], dtl = v[r][6], dtu = v[r][7], rdl = v[r][8], rdu = v[r][9];
-                        double gt = v[r][10];
-                        double rml, rmu;
-                        gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
-                        gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
-                        GT[(size_t)k * 18 + j] = gt;
-                        RW[(size_t)k * 12 + j] = v[r][11];
-                        gst(G3 + (size_t)k * W3 + O_RM + j, rml); gst(G3 + (size_t)k * W3 + O_RM + 12 + j, rmu);
-                    }
-                }
-            });
-        }
-        ex.wpar([&](int lane) {
-            for (int e = lane; e < NS * 6; e += NT) {
-                const int k = e / 6, j = e - k * 6;
-                GT[(size_t)k * 18 + 12 + j] = gld(G3 + (size_t)k * W3 + O_RG + 12 + j);
-            }
-        });
-        ex.barrier();
-        // ---- c_k = gt_x + A' w - Kfb' (gt_u + B' w) -> resident p array (stage N: p_N = gt_x)
-        ex.wpar([&](int lane) {
-            for (int e = lane; e < items; e += NT) {
-                const int k = e / NX, j = e - k * NX;
-                const double *gt = GT + (size_t)k * 18, *w = RW + (size_t)k * 12, *kf = rm.K + (size_t)k * 72;
-                double vv = gt[6 + j];
-                if (k < Nl) {
-                    vv += (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
-#pragma unroll
-                    for (int m = 0; m < 6; m++) vv -= kf[m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
-                }
-                rm.P[(size_t)k * 12 + j] = vv;
-            }
-        });
-        ex.barrier();
-        // operands of the last phase (R~^-1 row, rb), issued before the recursion
         typename Ex::template PerLane<double> ld[R][7];
-        auto issue = [&](int base) {
-            ex.wpar([&](int lane) {
+        const int nseg = SEG ? (Nl + SEG_T - 1) / SEG_T : 1;
+        for (int sg = nseg - 1; sg >= 0; sg--) {
+            const int kb = SEG ? sg * SEG_T : 0;
+            const int nt = ex.uni(SEG ? imin(SEG_T, Nl - kb) : Nl);
+            const bool top = kb + nt == Nl;
+            const int nsi = nt + (top ? 1 : 0);
+            const int items = nsi * NB;
+            if (SEG) {
+                const int c0 = kb / SEG_L, nc = (nt + SEG_L - 1) / SEG_L;
+                copies([&](int lane, auto nl) {
+                    constexpr int NL = decltype(nl)::value;
+                    copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
+                    copy_lanes<144, 0, 144, 144, true, NL>(rm.PHI, ex.smem().w.PH, c0, c0 + nc - 1, lane);
+                });
+            }
+            // ---- rm, gt of every bounded component (+ w_k into LDS); gt of the velocity components is rg
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    double v[R][12];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = imin(base + r * NT + lane, items - 1), k = e / NX, j = e - k * NX, i6 = j < 6 ? j : j - 6;
-                    const double *ri = G4 + (size_t)k * W4 + O_RI + i6 * 6;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) ld[r][m].at(lane) = gld(ri + m);
-                    ld[r][6].at(lane) = gld(G2 + (size_t)k * W2 + O_RB + j);
-                }
-            });
-        };
-        issue(0);
-        PROF_T0(ts);
-        rs_recursion<false>(rm, rm.P, xch, xs);
-        ex.barrier();
-        PROF_ADD(PF_SEQ_BWD, ts);
-        // ---- h_u,k = gt_u + B'(p_{k+1} + w_k) ; R~^-1 h_u and e = rb - B R~^-1 h_u for the forward sweep
-        for (int base = 0; base < items; base += R * NT) {
-            if (base > 0) issue(base);
-            ex.wpar([&](int lane) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = base + r * NT + lane;
-                    if (e < items) {
-                        const int k = e / NX, j = e - k * NX, i6 = j < 6 ? j : j - 6;
-                        double vh = 0.0, ee = 0.0;
-                        if (k < Nl) {
-                            const double *gt = GT + (size_t)k * 18, *w = RW + (size_t)k * 12, *pn = rm.P + (size_t)(k + 1) * 12;
-                            double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-                            for (int m = 0; m < 6; m += 2) {
-                                const double h0 = gt[m] + P.b1[m] * (pn[m] + w[m]) + P.b2[m] * (pn[6 + m] + w[6 + m]);
-                                const double h1 = gt[m + 1] + P.b1[m + 1] * (pn[m + 1] + w[m + 1]) + P.b2[m + 1] * (pn[7 + m] + w[7 + m]);
-                                v0 += ld[r][m].at(lane) * h0; v1 += ld[r][m + 1].at(lane) * h1;
-                            }
-                            vh = v0 + v1;
-                            ee = ld[r][6].at(lane) - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
-                        }
-                        if (j < 6) rm.VH[(size_t)k * 6 + j] = vh;
-                        rm.E[(size_t)k * 12 + j] = ee;
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), kl = e / NB, j = e - kl * NB, k = kb + kl;
+                        const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
+                        v[r][0] = gld(g1 + O_QLAM + j); v[r][1] = gld(g1 + O_QLAM + 12 + j);
+                        v[r][2] = gld(g1 + O_QT + j);   v[r][3] = gld(g1 + O_QT + 12 + j);
+                        v[r][4] = gld(g3 + O_DLAM + j); v[r][5] = gld(g3 + O_DLAM + 12 + j);
+                        v[r][6] = gld(g3 + O_DT + j);   v[r][7] = gld(g3 + O_DT + 12 + j);
+                        v[r][8] = gld(g3 + O_RD + j);   v[r][9] = gld(g3 + O_RD + 12 + j);
+                        v[r][10] = gld(g3 + O_RG + j);
+                        v[r][11] = gld(G4 + (size_t)k * W4 + O_WV + j);
                     }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int kl = e / NB, j = e - kl * NB, k = kb + kl;
+                            const bool hc = j < 6 ? k < Nl : (k >= 1 && k < Nl);
+                            const bool blo = hc && sm.bon[j] != 0.0, bhi = hc && sm.bon[12 + j] != 0.0;
+                            const double ll = v[r][0], lu = v[r][1], tl = v[r][2], tu = v[r][3];
+                            const double dll = v[r][4], dlu = v[r][5], dtl = v[r][6], dtu = v[r][7], rdl = v[r][8], rdu = v[r][9];
+                            double gt = v[r][10];
+                            double rml, rmu;
+                            gt += ipm::corrector_side(blo, ll, tl, dll, dtl, rdl, sigma_mu, rml);
+                            gt -= ipm::corrector_side(bhi, lu, tu, dlu, dtu, rdu, sigma_mu, rmu);
+                            GT[(size_t)kl * 18 + j] = gt;
+                            RW[(size_t)kl * 12 + j] = v[r][11];
+                            gst(G3 + (size_t)k * W3 + O_RM + j, rml); gst(G3 + (size_t)k * W3 + O_RM + 12 + j, rmu);
+                        }
+                    }
+                });
+            }
+            ex.wpar([&](int lane) {
+                for (int e = lane; e < nsi * 6; e += NT) {
+                    const int kl = e / 6, j = e - kl * 6;
+                    GT[(size_t)kl * 18 + 12 + j] = gld(G3 + (size_t)(kb + kl) * W3 + O_RG + 12 + j);
                 }
             });
+            ex.barrier();
+            // ---- c_k = gt_x + A' w - Kfb' (gt_u + B' w) -> resident p array (stage N: p_N = gt_x; a lower segment's end state: p
+            //      handed down from the segment above)
+            ex.wpar([&](int lane) {
+                for (int e = lane; e < items; e += NT) {
+                    const int kl = e / NX, j = e - kl * NX, k = kb + kl;
+                    const double *gt = GT + (size_t)kl * 18, *w = RW + (size_t)kl * 12, *kf = rm.K + (size_t)imin(kl, nt - 1) * 72;
+                    double vv = gt[6 + j];
+                    if (k < Nl) {
+                        vv += (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
+#pragma unroll
+                        for (int m = 0; m < 6; m++) vv -= kf[m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
+                    }
+                    rm.P[(size_t)kl * 12 + j] = vv;
+                }
+                if (SEG && !top && lane < NX) rm.P[(size_t)nt * 12 + lane] = pin[lane];
+            });
+            ex.barrier();
+            // operands of the last phase (R~^-1 row, rb), issued before the recursion
+            auto issue = [&](int base) {
+                ex.wpar([&](int lane) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), kl = e / NX, j = e - kl * NX, i6 = j < 6 ? j : j - 6, k = kb + kl;
+                        const double *ri = G4 + (size_t)k * W4 + O_RI + i6 * 6;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) ld[r][m].at(lane) = gld(ri + m);
+                        ld[r][6].at(lane) = gld(G2 + (size_t)k * W2 + O_RB + j);
+                    }
+                });
+            };
+            issue(0);
+            PROF_T0(ts);
+            rs_recursion<false>(rm, rm.P, xch, xs, nt);
+            ex.barrier();
+            PROF_ADD(PF_SEQ_BWD, ts);
+            // ---- h_u,k = gt_u + B'(p_{k+1} + w_k) ; R~^-1 h_u and e = rb - B R~^-1 h_u for the forward sweep
+            for (int base = 0; base < items; base += R * NT) {
+                if (base > 0) issue(base);
+                ex.wpar([&](int lane) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int kl = e / NX, j = e - kl * NX, i6 = j < 6 ? j : j - 6, k = kb + kl;
+                            double vh = 0.0, ee = 0.0;
+                            if (k < Nl) {
+                                const double *gt = GT + (size_t)kl * 18, *w = RW + (size_t)kl * 12, *pn = rm.P + (size_t)(kl + 1) * 12;
+                                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                                for (int m = 0; m < 6; m += 2) {
+                                    const double h0 = gt[m] + P.b1[m] * (pn[m] + w[m]) + P.b2[m] * (pn[6 + m] + w[6 + m]);
+                                    const double h1 = gt[m + 1] + P.b1[m + 1] * (pn[m + 1] + w[m + 1]) + P.b2[m + 1] * (pn[7 + m] + w[7 + m]);
+                                    v0 += ld[r][m].at(lane) * h0; v1 += ld[r][m + 1].at(lane) * h1;
+                                }
+                                vh = v0 + v1;
+                                ee = ld[r][6].at(lane) - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
+                            }
+                            if (j < 6) rm.VH[(size_t)kl * 6 + j] = vh;
+                            rm.E[(size_t)kl * 12 + j] = ee;
+                        }
+                    }
+                });
+            }
+            ex.barrier();
+            if (SEG) {
+                // what the final forward sweep reads of this segment goes back to the HBM record; p at its first stage goes down
+                copies([&](int lane, auto nl) {
+                    constexpr int NL = decltype(nl)::value;
+                    copy_lanes<6, O_VH, W4, 6, false, NL>(rm.VH, G4, kb, kb + nsi - 1, lane);
+                    copy_lanes<12, O_E, W4, 12, false, NL>(rm.E, G4, kb, kb + nsi - 1, lane);
+                    copy_lanes<12, O_PV, W4, 12, false, NL>(rm.P, G4, kb, kb + nsi - 1, lane);
+                    if (lane < NX) pin[lane] = rm.P[lane];
+                });
+            }
         }
-        ex.barrier();
         PROF_ADD(PF_BWD, t0);
     }
 
@@ -2012,6 +2103,7 @@ struct Engine {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
         const bool res = resident_ok();   // the horizon's factor fits the LDS pool: resident sweeps
+        const bool seg = segment_ok();    // it does not, but a segment of it does (whole pool of a CU): segment-resident sweeps
         residual_direct(0, 0.0);
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
@@ -2033,18 +2125,23 @@ struct Engine {
             const bool has_bounds = ex.uni(nc > 0);
             double a_aff;
             if (res) {
-                fact_pass_t<true>();
-                a_aff = has_bounds ? fwd_resident<true>() : fwd_resident<false>();
+                fact_pass_t<1>();
+                a_aff = has_bounds ? fwd_resident<true, false>() : fwd_resident<false, false>();
+            } else if (seg) {
+                fact_pass_t<2>();
+                a_aff = has_bounds ? fwd_resident<true, true>() : fwd_resident<false, true>();
             } else {
-                fact_pass_t<false>();
+                fact_pass_t<0>();
                 a_aff = has_bounds ? forward_step_pass<true>() : forward_step_pass<false>();
             }
             if (has_bounds) {
-                const double S0 = res ? ex.uni(sm.cen[1]) : ex.get1(sm.red[1]), S1 = res ? ex.uni(sm.cen[2]) : ex.get1(sm.red[2]),
-                             S2 = res ? ex.uni(sm.cen[3]) : ex.get1(sm.red[3]);
+                const bool rs = res || seg;
+                const double S0 = rs ? ex.uni(sm.cen[1]) : ex.get1(sm.red[1]), S1 = rs ? ex.uni(sm.cen[2]) : ex.get1(sm.red[2]),
+                             S2 = rs ? ex.uni(sm.cen[3]) : ex.get1(sm.red[3]);
                 const double mu_aff = (S0 + a_aff * (S1 + a_aff * S2)) / nc;
                 const double sigma = ipm::sigma(mu_aff, mu);
-                if (res) { corr_resident(sigma * mu); alpha = fwd_resident<false>(); }
+                if (res) { corr_resident<false>(sigma * mu); alpha = fwd_resident<false, false>(); }
+                else if (seg) { corr_resident<true>(sigma * mu); alpha = fwd_resident<false, true>(); }
                 else { corrector_bwd_pass(sigma * mu); alpha = forward_step_pass<false>(); }
             } else {
                 alpha = a_aff;
@@ -2246,7 +2343,7 @@ struct Engine {
         int log_lo = step0 == 0 ? 0 : step0 + 1;   // first log column this launch produces
         if (step0 == 0) {
             // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0 (SURVEY A.7 iv)
-            const size_t tot = (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES;
+            const size_t tot = ws_doubles_per_instance(N);
             ex.par([&](int lane) {
                 for (size_t e = lane; e < tot; e += NT) w.G1[e] = 0.0;  // G1 is the workspace base
             });

@@ -135,14 +135,18 @@ struct Outputs {
 
 // One instance's workspace: five stage-major group arrays + persistent scalars.
 struct Ws {
-    double *G1, *G2, *G3, *G4, *G5, *state;
+    double *G1, *G2, *G3, *G4, *G5, *PH, *state;
 };
+// Segmented residency of the latency engine (horizons whose Riccati factor does not fit a CU's LDS): the solve sweeps hold the
+// factor of one SEGMENT of SEG_T transitions at a time (16 chunks of SEG_L); PH keeps the chunk transition matrices (12x12 each).
+constexpr int SEG_L = 7, SEG_T = 16 * SEG_L;
+MPC_HD size_t ws_phi_doubles(int N) { return (size_t)((N + SEG_L - 1) / SEG_L + 1) * 144; }
 
 // offset of entry (r, c), r <= c, of a symmetric 12x12 matrix stored as its upper triangle by rows
 MPC_HD int tri(int r, int c) { return r * 12 - (r * (r - 1)) / 2 + (c - r); }
 MPC_HD int tri_sym(int i, int j) { return i <= j ? tri(i, j) : tri(j, i); }
 
-MPC_HD size_t ws_doubles_per_instance(int N) { return (size_t)(N + 1) * STAGE_DOUBLES + STATE_DOUBLES; }
+MPC_HD size_t ws_doubles_per_instance(int N) { return (size_t)(N + 1) * STAGE_DOUBLES + ws_phi_doubles(N) + STATE_DOUBLES; }
 
 MPC_HD Ws ws_carve(double *base, int N)
 {
@@ -154,6 +158,7 @@ MPC_HD Ws ws_carve(double *base, int N)
     w.G3 = p; p += n1 * W3;
     w.G4 = p; p += n1 * W4;
     w.G5 = p; p += n1 * W5;
+    w.PH = p; p += ws_phi_doubles(N);
     w.state = p;
     return w;
 }
