@@ -282,7 +282,7 @@ struct Engine {
     struct ResMap {
         double *K, *VH, *E, *P, *PHI;   // persistent: [NS][72], [NS][6], [NS][12], [NS][12], [J][144]
         double *scr;                    // scratch below them (fact: chunk buffers; sweeps: dx / gt / w / hand-over slots)
-        int scr_n, L;
+        int scr_n, L, J, T;             // chunk length, lane groups in use, transitions the maps hold (J * L; the horizon when resident)
     };
     static constexpr int RS_GROUPS = (NT / 16) < 16 ? (NT / 16) : 16;
     // items a lane holds in flight per batch, sized so that ONE batch covers N ~ 105 at this lane count (more lanes: fewer items each,
@@ -306,14 +306,17 @@ struct Engine {
         m.P = m.E + (size_t)NS * 12;
         m.PHI = m.P + (size_t)NS * 12;
         m.L = (Nl + RS_GROUPS - 1) / RS_GROUPS;
+        m.J = RS_GROUPS;
+        m.T = Nl;
         return m;
     }
     // SEGMENT map: the same arrays sized for one segment of SEG_T transitions (+ its end state), chunk length SEG_L
     MPC_HD ResMap seg_map() const
     {
         const int pool_n = ex.uni(ex.smem().pool_n);
-        constexpr int NSS = SEG_T + 1;
-        const int persist = NSS * RS_PER_STAGE + RS_GROUPS * 144;
+        const bool full = pool_n >= SEG_POOL_FULL;
+        const int Lc = full ? SEG_L_FULL : SEG_L_HALF, Jc = imin(full ? SEG_J_FULL : SEG_J_HALF, RS_GROUPS), NSS = Lc * Jc + 1;
+        const int persist = NSS * RS_PER_STAGE + Jc * 144;
         ResMap m;
         m.scr = ex.pool();
         m.scr_n = pool_n - persist;
@@ -322,7 +325,7 @@ struct Engine {
         m.E = m.VH + (size_t)NSS * 6;
         m.P = m.E + (size_t)NSS * 12;
         m.PHI = m.P + (size_t)NSS * 12;
-        m.L = SEG_L;
+        m.L = Lc; m.J = Jc; m.T = Lc * Jc;
         return m;
     }
     // horizons beyond the resident limit, with a whole CU's pool: segment-wise residency (the factor goes through HBM, the sweeps
@@ -332,9 +335,10 @@ struct Engine {
 #ifdef MPCB_NO_RESIDENT
         return false;
 #else
-        const int pool_n = ex.uni(ex.smem().pool_n);
-        const int scr = pool_n - ((SEG_T + 1) * RS_PER_STAGE + RS_GROUPS * 144);
-        return ex.uni(RS_GROUPS == 16 && !resident_ok() && scr >= (SEG_T + 1) * 30 + 2 * RS_GROUPS * 12 + 64);
+        // (with half a pool -- two simulations per CU -- segments of 8 x 5 transitions fit, but lose to the streaming sweeps there:
+        // batch 512, N = 100: 592 k vs 752 k steps/s; N = 200: 238 k vs 282 k: the segment loads are exposed and short)
+        const ResMap m = seg_map();
+        return ex.uni(RS_GROUPS >= 8 && ex.smem().pool_n >= SEG_POOL_FULL && !resident_ok() && m.scr_n >= (m.T + 1) * 30 + 2 * RS_GROUPS * 12 + 64);
 #endif
     }
     MPC_HD bool resident_ok() const
@@ -1195,7 +1199,7 @@ struct Engine {
                     // transition matrix Phi_c <- Phi_c Acl_k (lane i < 12 holds row i in registers), k descending
 #ifndef MPCB_DIAG_NO_PHI
                     if (lane < WAVE) {
-                        const int L = SEG ? SEG_L : rm.L;
+                        const int L = SEG ? seg_map().L : rm.L;
                         for (int k = imin(k1, Nl - 1); k >= k0; k--) {
                             ex.await(&sm.prog, Nl - k);
                             const double *kk = RES ? rm.K + (size_t)k * 72 : vf_of(ci) + (size_t)(k - k0) * WF - FO + O_K;
@@ -1704,13 +1708,13 @@ struct Engine {
             const int c = lane >> 4, i = lane & 15;
             const int ks = c * L, ke = imin(ks + L, Nl);
             g_ks.at(lane) = ks;
-            g_n.at(lane) = (lane < RS_GROUPS * 16 && i < NX && ke > ks) ? ke - ks : 0;
+            g_n.at(lane) = (lane < rm.J * 16 && i < NX && ke > ks) ? ke - ks : 0;
         });
         auto sweep = [&](auto store_tag) {
             constexpr bool STORE = decltype(store_tag)::value;
             ex.wpar([&](int lane) {
                 const int c = lane >> 4, i = lane & 15;
-                if (lane < RS_GROUPS * 16 && i < NX) {
+                if (lane < rm.J * 16 && i < NX) {
                     const double v = STORE ? xs[c * 12 + i] : 0.0;
                     z.at(lane) = v;
                     xch[c * 12 + i] = v;
@@ -1794,7 +1798,7 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(ex.smem().n_hor);
         const ResMap rm = SEG ? seg_map() : res_map();
-        const int NSL = SEG ? SEG_T + 1 : Nl + 1;       // states the maps hold
+        const int NSL = rm.T + 1;       // states the maps hold
         double *X = rm.scr, *xch = X + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *xin = xs + RS_GROUPS * 12;
         constexpr int R = rounds_for(6);
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
@@ -1803,8 +1807,8 @@ struct Engine {
         constexpr int RP = AFFINE ? 1 : RS_ROUNDS;
         typename Ex::template PerLane<double> pmr[RP][12];
         ex.wpar([&](int lane) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; });
-        for (int kb = 0; kb == 0 || kb < Nl; kb += SEG ? SEG_T : Nl + 1) {
-            const int nt = ex.uni(SEG ? imin(SEG_T, Nl - kb) : Nl);          // transitions of this segment
+        for (int kb = 0; kb == 0 || kb < Nl; kb += SEG ? rm.T : Nl + 1) {
+            const int nt = ex.uni(SEG ? imin(rm.T, Nl - kb) : Nl);          // transitions of this segment
             const int nsi = nt + (kb + nt == Nl ? 1 : 0);                    // stages with items: the end state only in the last segment
             const int items = nsi * 6;        // joint items (k, j): the bounded components u_j and q_j together
             const int items_pi = nsi * NB;    // dpi items (k, state component)
@@ -1840,7 +1844,7 @@ struct Engine {
             };
             if (SEG) {
                 // this segment's factor and chunk transition matrices: HBM -> the resident arrays (coalesced bursts)
-                const int c0 = kb / SEG_L, nc = (nt + SEG_L - 1) / SEG_L;
+                const int c0 = kb / rm.L, nc = (nt + rm.L - 1) / rm.L;
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
                     copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
@@ -1954,20 +1958,20 @@ struct Engine {
         const InstParams &P = sm.P;
         const int Nl = ex.uni(ex.smem().n_hor);
         const ResMap rm = SEG ? seg_map() : res_map();
-        const int NSL = SEG ? SEG_T + 1 : Nl + 1;
+        const int NSL = rm.T + 1;
         double *GT = rm.scr, *RW = GT + (size_t)NSL * 18, *xch = RW + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *pin = xs + RS_GROUPS * 12;
         constexpr int R = RS_ROUNDS;
         double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
         typename Ex::template PerLane<double> ld[R][7];
-        const int nseg = SEG ? (Nl + SEG_T - 1) / SEG_T : 1;
+        const int nseg = SEG ? (Nl + rm.T - 1) / rm.T : 1;
         for (int sg = nseg - 1; sg >= 0; sg--) {
-            const int kb = SEG ? sg * SEG_T : 0;
-            const int nt = ex.uni(SEG ? imin(SEG_T, Nl - kb) : Nl);
+            const int kb = SEG ? sg * rm.T : 0;
+            const int nt = ex.uni(SEG ? imin(rm.T, Nl - kb) : Nl);
             const bool top = kb + nt == Nl;
             const int nsi = nt + (top ? 1 : 0);
             const int items = nsi * NB;
             if (SEG) {
-                const int c0 = kb / SEG_L, nc = (nt + SEG_L - 1) / SEG_L;
+                const int c0 = kb / rm.L, nc = (nt + rm.L - 1) / rm.L;
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
                     copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);

@@ -139,8 +139,9 @@ struct Ws {
 };
 // Segmented residency of the latency engine (horizons whose Riccati factor does not fit a CU's LDS): the solve sweeps hold the
 // factor of one SEGMENT of SEG_T transitions at a time (16 chunks of SEG_L); PH keeps the chunk transition matrices (12x12 each).
-constexpr int SEG_L = 7, SEG_T = 16 * SEG_L;
-MPC_HD size_t ws_phi_doubles(int N) { return (size_t)((N + SEG_L - 1) / SEG_L + 1) * 144; }
+// Segment geometry by pool size: a whole CU's pool holds 16 chunks of 7 transitions, half a pool (two simulations per CU) 8 chunks of 5.
+constexpr int SEG_L_FULL = 7, SEG_J_FULL = 16, SEG_L_HALF = 5, SEG_J_HALF = 8, SEG_POOL_FULL = 17000;
+MPC_HD size_t ws_phi_doubles(int N) { return (size_t)((N + SEG_L_HALF - 1) / SEG_L_HALF + 1) * 144; }
 
 // offset of entry (r, c), r <= c, of a symmetric 12x12 matrix stored as its upper triangle by rows
 MPC_HD int tri(int r, int c) { return r * 12 - (r * (r - 1)) / 2 + (c - r); }
