@@ -1,6 +1,6 @@
 // mpc_pack.h -- host-side packing of one Simulator(**config) (simulator.py:18-35) into the
 // device parameter record.  The C-ABI takes, per instance, MPCB_NPARAM doubles:
-//   [0] dt [1] tol [2] qp_tol [3] w_u [4] w_qddot [5] px_ref [6] vy_ref [7] reserved
+//   [0] dt [1] tol [2] qp_tol [3] w_u [4] w_qddot [5] px_ref [6] vy_ref [7] plant integrator (0 RK4, 1 Euler, 2 RK2, 3 RK3)
 //   [8..13] wcv  [14..19] q_0  [20..25] qdot_0  [26..31] q_min  [32..37] q_max
 //   [38..43] qdot_min  [44..49] qdot_max  [50..55] surface coeffs a..f  [56..60] task weights
 //   [61] nlp_solver_tol_eq [62] nlp_solver_tol_ineq [63] nlp_solver_tol_comp  (0: same as [1] = tol_stat)

@@ -62,13 +62,14 @@ def main():
                       "devices": ndev, "weighted_rmse_first": res[0]["summary"]["weighted_rmse"]}
         else:
             assert res == []
-    except Exception as e:   # report, then fail the process
-        ok, detail = False, {"error": repr(e)}
+    except Exception as e:   # report and exit non-zero WITHOUT entering another collective: the other rank may be gone
+        print("DIST_ENGINE_CHECK " + json.dumps({"ok": False, "rank": rank, "error": repr(e)}), flush=True)
+        sys.exit(1)
     dist.barrier()
     if rank == 0:
         print("DIST_ENGINE_CHECK " + json.dumps({"ok": ok, **detail}), flush=True)
     dist.destroy_process_group()
-    sys.exit(0 if ok else 1)
+    sys.exit(0)
 
 
 if __name__ == "__main__":
