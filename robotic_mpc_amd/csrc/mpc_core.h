@@ -1804,8 +1804,7 @@ struct Engine {
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
         typename Ex::template PerLane<double> ld[R][16];
         typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
-        constexpr int RP = AFFINE ? 1 : RS_ROUNDS;
-        typename Ex::template PerLane<double> pmr[RP][12];
+        constexpr int RP = RS_ROUNDS;
         ex.wpar([&](int lane) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; });
         for (int kb = 0; kb == 0 || kb < Nl; kb += SEG ? rm.T : Nl + 1) {
             const int nt = ex.uni(SEG ? imin(rm.T, Nl - kb) : Nl);          // transitions of this segment
@@ -1830,18 +1829,6 @@ struct Engine {
                     }
                 });
             };
-            // final sweep: row j of the packed P_k for the dpi items, straight from HBM (issued with the other operands)
-            auto issue_pi = [&](int base) {
-                ex.wpar([&](int lane) {
-#pragma unroll
-                    for (int r = 0; r < RP; r++) {
-                        const int e = imin(base + r * NT + lane, items_pi - 1), kl = e / NB, j = e - kl * NB;
-                        const double *g4 = G4 + (size_t)(kb + kl) * W4 + O_PM;
-#pragma unroll
-                        for (int i = 0; i < NX; i++) pmr[r][i].at(lane) = gld(g4 + tri_sym(j, i));
-                    }
-                });
-            };
             if (SEG) {
                 // this segment's factor and chunk transition matrices: HBM -> the resident arrays (coalesced bursts)
                 const int c0 = kb / rm.L, nc = (nt + rm.L - 1) / rm.L;
@@ -1855,7 +1842,6 @@ struct Engine {
                 });
             }
             issue(0);
-            if (!AFFINE) issue_pi(0);
             PROF_T0(ts);
             rs_recursion<true>(rm, X, xch, xs, nt, kb > 0 ? xin : nullptr);
             ex.barrier();
@@ -1905,9 +1891,17 @@ struct Engine {
             }
             if (!AFFINE) {
                 for (int base = 0; base < items_pi; base += RP * NT) {
-                    // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1})
-                    if (base > 0) issue_pi(base);
+                    // dpi_{k-1} = p_k + P_k dx_k (the DPI slot of stage k holds dpi_{k-1}): row j of the packed P_k straight from HBM
+                    // (loaded here, not with the other operands: held across the recursion they cost the 8-wavefront build its registers)
                     ex.wpar([&](int lane) {
+                        double pm[RP][12];
+#pragma unroll
+                        for (int r = 0; r < RP; r++) {
+                            const int e = imin(base + r * NT + lane, items_pi - 1), kl = e / NB, j = e - kl * NB;
+                            const double *g4 = G4 + (size_t)(kb + kl) * W4 + O_PM;
+#pragma unroll
+                            for (int i = 0; i < NX; i++) pm[r][i] = gld(g4 + tri_sym(j, i));
+                        }
 #pragma unroll
                         for (int r = 0; r < RP; r++) {
                             const int e = base + r * NT + lane;
@@ -1918,7 +1912,7 @@ struct Engine {
                                 if (k >= 1) {
                                     double s0 = rm.P[(size_t)kl * 12 + j], s1 = 0.0;
 #pragma unroll
-                                    for (int i = 0; i < NX; i += 2) { s0 += pmr[r][i].at(lane) * dxk[i]; s1 += pmr[r][i + 1].at(lane) * dxk[i + 1]; }
+                                    for (int i = 0; i < NX; i += 2) { s0 += pm[r][i] * dxk[i]; s1 += pm[r][i + 1] * dxk[i + 1]; }
                                     v = s0 + s1;
                                 }
                                 gst(G3 + (size_t)k * W3 + O_DPI + j, v);

@@ -107,10 +107,15 @@ def test_asm_scanner_detects_empty_exec_reload():
                       "\ts_or_b64 exec, exec, s[8:9]", "\tv_accvgpr_read_b32 v61, a11"])
     assert len(mod.scan(bad)) == 1 and mod.scan(bad)[0][0] == "_Z3foov"
     assert mod.scan(good) == []
+    # second check: register spills in the item-parallel passes (a scratch reload drains every prefetch in flight)
+    hot = "_ZN4mpcb6EngineI7DevExecILi8ELi1EEE12fwd_residentILb0ELb0EEEdv"
+    spilled = "\n".join([hot + ":"] + ["\tscratch_load_dword v1, off, s32"] * 12 + [".Lfunc_end0:", "_Z5otherv:", "\tscratch_load_dword v1, off, s32"])
+    assert mod.scratch_ops(spilled) == {hot: 12}
 
 
 def test_generated_isa_has_no_vector_op_under_empty_exec():
-    """The shipped kernel source compiles (gfx950) without the miscompile pattern."""
+    """The shipped kernel source compiles (gfx950) without the miscompile pattern and without register spills in the hot
+    item-parallel / recursion passes of the 4- and 8-wavefront builds."""
     import subprocess
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_asm.py")], capture_output=True, text=True,

@@ -289,3 +289,34 @@ def test_solver_failures_are_data_and_match_the_oracle(eng, orc, ur10, ur10_rb, 
             np.testing.assert_allclose(out[k][i], ref[k], atol=1e-8, rtol=0, err_msg=f"{name} {k}")
     assert np.isfinite(out["z"]).all()
     assert np.array_equal(out["z"][0], out["z"][1])
+
+
+@pytest.mark.parametrize("N,T", [(100, 0.5), (200, 0.3), (300, 0.15)])
+def test_resident_segment_and_streaming_sweeps_agree(orc, ur10, ur10_rb, monkeypatch, N, T):
+    """Round 3: the latency engine has three sweep implementations behind one launch -- the factor LDS-resident with
+    chunk-parallel recursions (N <= ~125, a whole CU's pool), the same one 112-transition SEGMENT at a time (longer
+    horizons), and the streaming sweeps (half a pool: two simulations per CU).  The same simulations through the default
+    geometry (resident at N = 100, segments at N = 200 / 300) and through MPCB_SIMS_PER_CU=2 (streaming): identical solver
+    decisions at every step, trajectories within 1e-11 of each other, both within 1e-9 of the oracle."""
+    from robotic_mpc_amd import engine
+
+    cfgs = _jitter(5, seed=7 * N, prediction_horizon=N, simulation_time=T)
+    outs = {}
+    for name, env in (("default", {}), ("streaming", {"MPCB_SIMS_PER_CU": "2"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = engine.MpcBatchEngine(0)
+        outs[name] = e.run(cfgs, ur10)
+        geo = e.launch_info()
+        e.close()
+        assert geo["engine"] == 0
+        assert (geo["pool_bytes"] > 100000) == (name == "default"), geo
+    a, b = outs["default"], outs["streaming"]
+    for k in ("status", "sqp_iter", "qp_iter"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("z", "u", "ee_pose", "errors"):
+        np.testing.assert_allclose(a[k], b[k], atol=1e-11, rtol=0, err_msg=k)
+    for i in (0, 4):
+        ref = orc.run(ur10_rb, orc.make_params(cfgs[i]))
+        _check(a, i, ref)
+        _check(b, i, ref)
