@@ -361,11 +361,40 @@ struct Engine {
     // Jacobian per stage (lane <-> stage), dynamics defect, cost = sum_k dt/2 r'Wr (acados
     // get_cost(), simulator.py:221) -- and evaluates acados' ocp_nlp_res_compute inf-norms
     // [stat, eq, ineq, comp] with the NLP multipliers (RTI: the QP's; SQP: the blended ones).
+    // One joint of the plant step (simulation_model.py:93-117): Euler / RK2 (midpoint) / RK3 / RK4 of z' = [qdot; -W (qdot - u)]
+    MPC_HD static void plant_rk(const InstParams &P, int j, double q, double v, double u, double &qn, double &vn)
+    {
+        const double wc = P.wcv[j], dt = P.dt;
+        const int integ = (int)P.integ;
+        const double k1q = v, k1v = -wc * v + wc * u;
+        const double v2 = v + 0.5 * dt * k1v;
+        const double k2q = v2, k2v = -wc * v2 + wc * u;
+        if (integ == 1) {
+            qn = q + dt * k1q; vn = v + dt * k1v;
+        } else if (integ == 2) {
+            qn = q + dt * k2q; vn = v + dt * k2v;
+        } else if (integ == 3) {
+            const double v3 = v - dt * k1v + 2.0 * dt * k2v;
+            const double k3q = v3, k3v = -wc * v3 + wc * u;
+            qn = q + (dt / 6) * (k1q + 4.0 * k2q + k3q); vn = v + (dt / 6) * (k1v + 4.0 * k2v + k3v);
+        } else {
+            const double v3 = v + 0.5 * dt * k2v;
+            const double k3q = v3, k3v = -wc * v3 + wc * u;
+            const double v4 = v + dt * k3v;
+            const double k4q = v4, k4v = -wc * v4 + wc * u;
+            qn = q + (dt / 6) * k1q + (dt / 3) * k2q + (dt / 3) * k3q + (dt / 6) * k4q;
+            vn = v + (dt / 6) * k1v + (dt / 3) * k2v + (dt / 3) * k3v + (dt / 6) * k4v;
+        }
+    }
+
     // Item-parallel (any horizon): the iterate is updated IN PLACE in HBM by 16-byte items, every
     // lane linearises one stage from operands it loads itself, and the residual norms are joint items (u_j, q_j, v_j together) --
     // no staging of the 96-column iterate record through LDS (81 KB per pass at N = 100), no copy-back.  The linearisation records
     // (60 doubles per stage) collect in LDS and leave with one coalesced store.
-    MPC_PASS double nlp_direct(double alpha, bool do_update, bool sqp_mult, double *res4)
+    // `do_plant` (SQP_RTI: this is the last pass of solve()): the plant step with u = solver.get(0,'u') and the FK / J qdot / task-error
+    // log of the NEW plant state (simulation_model.py:85-91) are one lane's work; they run here on a lane that has no stage to
+    // linearise, in the shadow of the linearisation, instead of alone after the solve (6 us per MPC step).  Results in sm.logv / sm.u0.
+    MPC_PASS double nlp_direct(double alpha, bool do_update, bool sqp_mult, double *res4, bool do_plant = false)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
@@ -467,6 +496,19 @@ struct Engine {
 #pragma unroll
                         for (int i = 0; i < W2_LIN; i++) rec[i] = 0.0;
                     }
+                }
+                if (do_plant && k0 == 0 && lane == NT - WAVE) {
+                    const double tp0 = ex.clock();
+                    double zn[12];
+                    for (int j = 0; j < 6; j++) {
+                        const double u = gld(G1 + O_U + j);                 // (stage 0, after the update above)
+                        plant_rk(P, j, sm.xhat[j], sm.xhat[6 + j], u, zn[j], zn[6 + j]);
+                        sm.u0[j] = u;
+                        sm.logv[24 + j] = zn[j]; sm.logv[30 + j] = zn[6 + j];
+                    }
+                    plant_log(rb, zn, sm.logv);
+                    task_errors(sm.P, rb, sm.logv, sm.logv + 15, sm.logv + 36);
+                    sm.ret[6] = ex.clock() - tp0;
                 }
                 ex.put_sum(sm.red[4], lane, csum);
             });
@@ -2282,8 +2324,10 @@ struct Engine {
     // One solver.solve() call (simulator.py:210-221).  On entry sm.xhat holds the feedback
     // state and G2 holds the linearisation at the current iterate when `lin_valid`; on exit it
     // is valid for the (new) iterate again, together with its cost and NLP residuals.
-    MPC_HD int nlp_step(bool &lin_valid, int *sqp_iter_out, int *qp_iter_out, double *res4, double *cost_out)
+    // `plant_done` (out): the plant step and the log of the new state were done inside the last NLP pass (SQP_RTI)
+    MPC_HD int nlp_step(bool &lin_valid, int *sqp_iter_out, int *qp_iter_out, double *res4, double *cost_out, bool *plant_done)
     {
+        *plant_done = false;
         PROF_T0(t0);
         int status = 0, sqp_iter = 0, qp_iter = 0, it = 0;
         double cost = lin_cost;
@@ -2297,7 +2341,8 @@ struct Engine {
             if (!ok) status = 4;  // ACADOS_QP_FAILURE, iterate untouched
             // residuals / cost are evaluated at the new iterate (acados get_residuals() for RTI,
             // get_cost()); this linearisation is reused by the next solve() call
-            cost = NLP_PASS(1.0, ok, false, res4);
+            cost = NLP_PASS(1.0, ok, false, res4, true);
+            *plant_done = true;
             lin_valid = true;
         } else {
             const double tol = ex.smem().P.tol, tol_eq = ex.smem().P.tol_eq, tol_in = ex.smem().P.tol_ineq, tol_co = ex.smem().P.tol_comp;
@@ -2353,7 +2398,7 @@ struct Engine {
                 if (lane < NX) sm.xhat[lane] = lane < 6 ? P.q0[lane] : P.qdot0[lane - 6];
                 if (lane < NU) sm.u0[lane] = P.qdot0[lane];  // u[:,0] = qdot_0 (simulator.py:81)
             });
-            log_lo = ex.uni(log_state(out, inst, 0, log_lo));
+            log_lo = ex.uni(log_state(out, inst, 0, log_lo, false));
         } else {
             ex.par([&](int lane) {
                 if (lane < NX) sm.xhat[lane] = w.state[lane];
@@ -2365,37 +2410,17 @@ struct Engine {
             int sqp_iter = 0, qp_iter = 0;
             double res4[4] = {0, 0, 0, 0}, cost = 0.0;
             const double t0 = ex.clock();
-            const int status = nlp_step(lin_valid, &sqp_iter, &qp_iter, res4, &cost);
+            bool plant_done = false;
+            const int status = nlp_step(lin_valid, &sqp_iter, &qp_iter, res4, &cost, &plant_done);
             const double t1 = ex.clock();
             PROF_T0(tp);
-            // u = solver.get(0,'u'); RK4 plant step (simulation_model.py:111-117)
+            // u = solver.get(0,'u'); RK4 plant step (simulation_model.py:111-117) -- unless the last NLP pass has done it
             ex.par([&](int lane) {
-                if (lane < 6) {
+                if (lane < 6 && !plant_done) {
                     const int j = lane;
-                    const double u = w.G1[O_U + j], wc = P.wcv[j], dt = P.dt;
-                    const double q = sm.xhat[j], v = sm.xhat[6 + j];
-                    // simulation_model.py:93-117: Euler / RK2 (midpoint) / RK3 / RK4 of z' = [qdot; -W(qdot - u)]
-                    const int integ = (int)P.integ;
-                    const double k1q = v, k1v = -wc * v + wc * u;
-                    const double v2 = v + 0.5 * dt * k1v;
-                    const double k2q = v2, k2v = -wc * v2 + wc * u;
+                    const double u = w.G1[O_U + j];
                     double qn, vn;
-                    if (integ == 1) {
-                        qn = q + dt * k1q; vn = v + dt * k1v;
-                    } else if (integ == 2) {
-                        qn = q + dt * k2q; vn = v + dt * k2v;
-                    } else if (integ == 3) {
-                        const double v3 = v - dt * k1v + 2.0 * dt * k2v;
-                        const double k3q = v3, k3v = -wc * v3 + wc * u;
-                        qn = q + (dt / 6) * (k1q + 4.0 * k2q + k3q); vn = v + (dt / 6) * (k1v + 4.0 * k2v + k3v);
-                    } else {
-                        const double v3 = v + 0.5 * dt * k2v;
-                        const double k3q = v3, k3v = -wc * v3 + wc * u;
-                        const double v4 = v + dt * k3v;
-                        const double k4q = v4, k4v = -wc * v4 + wc * u;
-                        qn = q + (dt / 6) * k1q + (dt / 3) * k2q + (dt / 3) * k3q + (dt / 6) * k4q;
-                        vn = v + (dt / 6) * k1v + (dt / 3) * k2v + (dt / 3) * k3v + (dt / 6) * k4v;
-                    }
+                    plant_rk(P, j, sm.xhat[j], sm.xhat[6 + j], u, qn, vn);
                     sm.logv[24 + j] = qn;
                     sm.logv[30 + j] = vn;
                     sm.u0[j] = u;
@@ -2413,9 +2438,10 @@ struct Engine {
             ex.par([&](int lane) {
                 if (lane < NX) sm.xhat[lane] = sm.logv[24 + lane];
             });
-            log_lo = ex.uni(log_state(out, inst, i + 1, log_lo));
+            log_lo = ex.uni(log_state(out, inst, i + 1, log_lo, plant_done));
             const double t2 = ex.clock();
-            ex.par([&](int lane) { if (lane == 0) out.plant_time[sb + i] = t2 - t1; });
+            // plant_time: what is left of it here + the plant lane's own time inside the NLP pass
+            ex.par([&](int lane) { if (lane == 0) out.plant_time[sb + i] = (t2 - t1) + (plant_done ? sm.ret[6] : 0.0); });
             PROF_ADD(PF_PLANT, tp);
         }
         if (log_lo <= step1) log_flush(out, inst, log_lo, step1);   // the columns of a partly filled block
@@ -2436,11 +2462,12 @@ struct Engine {
     // simulation_model.py:87-90: log state, input, FK pose, rpy, J*qdot at column `col`, plus the task errors of
     // Simulator.errors (simulator.py:265-344) of that column.  Columns collect in LDS (sm.logbuf) and leave as
     // contiguous runs of up to LOGB columns per row: `log_lo` = first column of the current block still in LDS.
-    MPC_PASS int log_state(const Outputs &out, int inst, int col, int log_lo)
+    // `computed`: sm.logv already holds the pose / rpy / J qdot / task errors of sm.xhat (done inside the last NLP pass)
+    MPC_PASS int log_state(const Outputs &out, int inst, int col, int log_lo, bool computed)
     {
         Smem &sm = ex.smem();
         const Robot &rb = sm.rb;
-        ex.par([&](int lane) {
+        if (!computed) ex.par([&](int lane) {
             if (lane == 0) {
                 double z[12];
 #pragma unroll

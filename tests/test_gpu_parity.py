@@ -66,7 +66,8 @@ def test_native_library_is_the_path(eng):
 
 @pytest.mark.parametrize("N,T,solver,B", [(20, 1.0, "SQP_RTI", 4), (10, 0.5, "SQP", 3), (100, 0.3, "SQP_RTI", 2),
                                            (1, 0.1, "SQP_RTI", 1), (2, 0.1, "SQP", 1), (130, 0.05, "SQP_RTI", 2),
-                                           (300, 0.03, "SQP_RTI", 1), (200, 0.02, "SQP", 1)])   # BASELINE configs[4] horizon: 10+ chunks per pass
+                                           (300, 0.03, "SQP_RTI", 1), (200, 0.02, "SQP", 1),    # BASELINE configs[4] horizon: segment-resident sweeps
+                                           (100, 0.1, "SQP", 2), (125, 0.05, "SQP_RTI", 1), (126, 0.05, "SQP_RTI", 1)])   # full SQP on the resident path (8 wavefronts); the resident / segment boundary
 def test_engine_matches_oracle(eng, orc, ur10, ur10_rb, N, T, solver, B):
     cfgs = _jitter(B, seed=N, prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
     out = eng.run(cfgs, ur10)
