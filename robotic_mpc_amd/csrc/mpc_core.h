@@ -328,6 +328,37 @@ struct Engine {
         m.L = Lc; m.J = Jc; m.T = Lc * Jc;
         return m;
     }
+    // REGISTER map (rs_recursion_reg): nothing of the factor in LDS -- only p (c -> p), the chunk transition matrices and scratch
+    MPC_HD ResMap reg_map() const
+    {
+        const int pool_n = ex.uni(ex.smem().pool_n);
+        constexpr int NSS = 16 * RL + 1;
+        const int persist = NSS * 12 + 16 * 144;
+        ResMap m;
+        m.scr = ex.pool();
+        m.scr_n = pool_n - persist;
+        m.K = nullptr; m.VH = nullptr; m.E = nullptr;
+        m.P = ex.pool() + m.scr_n;
+        m.PHI = m.P + (size_t)NSS * 12;
+        m.L = RL; m.J = 16; m.T = 16 * RL;
+        return m;
+    }
+    // MPCB_REG_MODE: 0 never, 1 (default) with half a CU's pool (two simulations per CU: batch 512, N = 100: 876 k steps/s against
+    // 760 k with the streaming sweeps, N = 200: 325 k against 277 k), 2 also with the whole pool instead of the LDS segments (level
+    // with them: N = 200 / 300, batch 256: 238 k / 138 k either way)
+#ifndef MPCB_REG_MODE
+#define MPCB_REG_MODE 1
+#endif
+    MPC_HD bool reg_ok() const
+    {
+#if defined(MPCB_NO_RESIDENT) || MPCB_REG_MODE == 0
+        return false;
+#else
+        const ResMap m = reg_map();
+        const bool full = ex.smem().pool_n >= SEG_POOL_FULL;
+        return ex.uni(RS_GROUPS == 16 && !resident_ok() && (MPCB_REG_MODE >= 2 || !full) && m.scr_n >= (m.T + 1) * 30 + 3 * 16 * 12 + 64);
+#endif
+    }
     // horizons beyond the resident limit, with a whole CU's pool: segment-wise residency (the factor goes through HBM, the sweeps
     // load it back one segment at a time and run chunk-parallel inside the segment)
     MPC_HD bool segment_ok() const
@@ -1241,7 +1272,7 @@ struct Engine {
                     // transition matrix Phi_c <- Phi_c Acl_k (lane i < 12 holds row i in registers), k descending
 #ifndef MPCB_DIAG_NO_PHI
                     if (lane < WAVE) {
-                        const int L = SEG ? seg_map().L : rm.L;
+                        const int L = SEG ? (reg_ok() ? RL : seg_map().L) : rm.L;
                         for (int k = imin(k1, Nl - 1); k >= k0; k--) {
                             ex.await(&sm.prog, Nl - k);
                             const double *kk = RES ? rm.K + (size_t)k * 72 : vf_of(ci) + (size_t)(k - k0) * WF - FO + O_K;
@@ -1827,24 +1858,198 @@ struct Engine {
         sweep(std::true_type{});
     }
 
+    // The same recursion with the factor in REGISTERS instead of LDS (chunks of exactly RL = 7 transitions): every lane of a group
+    // loads, once per sweep and straight from the HBM factor record, what it needs of K for ALL steps of its chunk -- forward: HALF a
+    // row of K (lanes i and i + 6 share row i and swap their partial dot products by a DPP row shift), 6 doubles per step, plus e_k;
+    // backward: column i, 6 doubles per step -- 49 doubles per lane.  The sweeps then need no LDS for the factor at all, so they run
+    // with half a pool (two simulations per CU) and at any horizon (segment by segment).  `kb`: first stage of the segment (HBM index).
+    static constexpr int RL = 7;
+    template <int T0, class F>
+    MPC_HD static void unroll_rl(F &&f)
+    {
+        if constexpr (T0 < RL) { f(std::integral_constant<int, T0>{}); unroll_rl<T0 + 1>(f); }
+    }
+    template <bool FWD>
+    MPC_HD void rs_recursion_reg(const ResMap &rm, double *vec, double *xch, double *xs, double *psl, int nt, int kb, const double *x0 = nullptr)
+    {
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(nt);
+        constexpr int L = RL;
+        const int Jused = (Nl + L - 1) / L;
+        const double *const G4 = ex.smem().w.G4;
+        typename Ex::template PerLane<double> z, pp;
+        typename Ex::template PerLane<D2> ab, bb;
+        typename Ex::template PerLane<double> kreg[RL][6], ereg[RL];
+        typename Ex::template PerLane<int> g_ks, g_n;
+        double b1r[6], b2r[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) { b1r[m] = P.b1[m]; b2r[m] = P.b2[m]; }
+        // chunk geometry, model constants, and this lane's share of K (and e) for every step of its chunk
+        ex.wpar([&](int lane) {
+            const int c = lane >> 4, i = lane & 15, i6 = i < 6 ? i : i - 6, j6 = i % 6;
+            const int ks = c * L, ke = imin(ks + L, Nl);
+            const int n = (lane < rm.J * 16 && i < NX && ke > ks) ? ke - ks : 0;
+            g_ks.at(lane) = ks; g_n.at(lane) = n;
+            D2 a; a.x = P.a12[j6]; a.y = P.a22[j6]; ab.at(lane) = a;
+            D2 b; b.x = P.b1[j6]; b.y = P.b2[j6]; bb.at(lane) = b;
+            unroll_rl<0>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const int k = kb + (FWD ? ks + t : ks + n - 1 - t);
+                if (t < n) {
+                    const double *g4 = G4 + (size_t)k * W4;
+                    if (FWD) {
+                        const double *kr = g4 + O_K + i6 * 12 + (i < 6 ? 0 : 6);
+#pragma unroll
+                        for (int j = 0; j < 6; j++) kreg[t][j].at(lane) = gld(kr + j);
+                        ereg[t].at(lane) = gld(g4 + O_E + i);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 6; m++) kreg[t][m].at(lane) = gld(g4 + O_K + m * 12 + i);
+                    }
+                }
+            });
+        });
+        auto sweep = [&](auto store_tag) {
+            constexpr bool STORE = decltype(store_tag)::value;
+            ex.wpar([&](int lane) {
+                const int c = lane >> 4, i = lane & 15;
+                if (lane < rm.J * 16 && i < NX) {
+                    const double v = STORE ? xs[c * 12 + i] : 0.0;
+                    z.at(lane) = v;
+                    xch[c * 12 + i] = v;
+                    if (STORE && FWD && c < Jused) vec[(size_t)c * L * 12 + i] = v;   // dx at the chunk's first stage
+                }
+            });
+            unroll_rl<0>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if (t < L && ex.uni(t < Nl)) {
+                    ex.wpar([&](int lane) {
+                        const int n = g_n.at(lane), ks = g_ks.at(lane);
+                        if (t < n) {
+                            const int c = lane >> 4, i = lane & 15, i6 = i < 6 ? i : i - 6;
+                            const double *zz = xch + c * 12;
+                            if (FWD) {
+                                // partial dot product of row i6 of K with this lane's half of the vector
+                                const D2 *z2 = reinterpret_cast<const D2 *>(zz + (i < 6 ? 0 : 6));
+                                const D2 v0 = z2[0], v1 = z2[1], v2 = z2[2];
+                                const double s0 = kreg[t][0].at(lane) * v0.x + kreg[t][2].at(lane) * v1.x + kreg[t][4].at(lane) * v2.x;
+                                const double s1 = kreg[t][1].at(lane) * v0.y + kreg[t][3].at(lane) * v1.y + kreg[t][5].at(lane) * v2.y;
+                                const double ph = s0 + s1;
+                                pp.at(lane) = ph;
+                                ex.share(psl + c * 12, i, ph);
+                            } else {
+                                const int k = ks + n - 1 - t;
+                                const D2 *z2 = reinterpret_cast<const D2 *>(zz);
+                                double zv[12];
+#pragma unroll
+                                for (int j = 0; j < NX; j += 2) { const D2 tt = z2[j >> 1]; zv[j] = tt.x; zv[j + 1] = tt.y; }
+                                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                                for (int m = 0; m < 6; m += 2) {
+                                    acc0 += kreg[t][m].at(lane) * (b1r[m] * zv[m] + b2r[m] * zv[6 + m]);
+                                    acc1 += kreg[t][m + 1].at(lane) * (b1r[m + 1] * zv[m + 1] + b2r[m + 1] * zv[7 + m]);
+                                }
+                                const D2 a = ab.at(lane);
+                                const double mine = zz[i], oq = zz[i6];
+                                const double at = i < 6 ? mine : a.x * oq + a.y * mine;
+                                z.at(lane) = vec[(size_t)k * 12 + i] + (at - (acc0 + acc1));
+                            }
+                        }
+                    });
+                    if (FWD) {
+                        ex.wpar([&](int lane) {
+                            const int n = g_n.at(lane);
+                            // (the DPP shift is executed by every lane of the wavefront: no lane-dependent branch around it)
+                            const int c = lane >> 4, i = lane & 15;
+                            const double mine = pp.at(lane);
+                            const double up = ex.shl6(psl + c * 12, i, mine), dn = ex.shr6(psl + c * 12, i, mine);
+                            if (t < n) {
+                                const double *zz = xch + c * 12;
+                                const int i6 = i < 6 ? i : i - 6;
+                                const double kd = i < 6 ? mine + up : dn + mine;        // lower half + upper half, in both lanes
+                                const D2 a = ab.at(lane), b = bb.at(lane);
+                                const double own = zz[i], ov = zz[i6 + 6];
+                                z.at(lane) = ereg[t].at(lane) + (i < 6 ? own + a.x * ov - b.x * kd : a.y * own - b.y * kd);
+                            }
+                        });
+                    }
+                    ex.wpar([&](int lane) {
+                        const int n = g_n.at(lane), ks = g_ks.at(lane);
+                        if (t < n) {
+                            const int c = lane >> 4, i = lane & 15, k = FWD ? ks + t : ks + n - 1 - t;
+                            const double v = z.at(lane);
+                            xch[c * 12 + i] = v;
+                            if (STORE) {
+                                if (FWD) { if (t + 1 < n || k + 1 == Nl) vec[(size_t)(k + 1) * 12 + i] = v; }
+                                else vec[(size_t)k * 12 + i] = v;
+                            }
+                        }
+                    });
+                }
+            });
+        };
+        sweep(std::false_type{});
+        ex.barrier();
+        // pass 2: chunk boundary values, one group (wavefront 0, lanes < 12); y_c = the slot pass 1 left
+        {
+            typename Ex::template PerLane<double> xr;
+            int cur = 0;
+            ex.seq([&](int lane) {
+                const double v = lane < NX ? (FWD ? (x0 ? x0[lane] : 0.0) : vec[(size_t)Nl * 12 + lane]) : 0.0;
+                xr.at(lane) = v;
+                if (lane < NX) ex.share(sm.pv[cur], lane, v);
+            });
+            for (int cc = 0; cc < Jused; cc++) {
+                const int c = FWD ? cc : Jused - 1 - cc, nxt = cur ^ 1;
+                ex.seq([&](int lane) {
+                    const int lc = lane < NX ? lane : 0;
+                    const double *ph = rm.PHI + (size_t)c * 144;
+                    double pr[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) pr[j] = FWD ? ph[lc * 12 + j] : ph[j * 12 + lc];
+                    const double y = xch[c * 12 + lc];
+                    const double own = xr.at(lane);
+                    double xv[12];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) xv[j] = ex.gather(sm.pv[cur], j, own);
+                    double s0 = y, s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; j += 2) { s0 += pr[j] * xv[j]; s1 += pr[j + 1] * xv[j + 1]; }
+                    const double v = s0 + s1;
+                    xr.at(lane) = v;
+                    if (lane < NX) { xs[c * 12 + lane] = own; ex.share(sm.pv[nxt], lane, v); }
+                });
+                cur = nxt;
+            }
+        }
+        ex.barrier();
+        sweep(std::true_type{});
+    }
+
     // Forward sweep on the resident factor: dx by rs_recursion, then item-parallel (lane <-> (stage, bounded component)):
     // du = -(R~^-1 h_u + K dx), dt, dlam (HPIPM compute_lam_t), largest feasible step, centering sums; the final sweep
     // also dpi_{k-1} = p_k + P_k dx_k and the whole Newton step to HBM.  Leaves alpha, S0, S1, S2 in sm.cen[0..3].
     // SEG: the factor of ONE SEGMENT of SEG_T transitions at a time (loaded from the HBM record the plain factorisation wrote),
     // segments in ascending order, dx handed from segment to segment; all LDS indices are local to the segment (kb = its first stage).
-    template <bool AFFINE, bool SEG>
+    // KREG (with SEG): nothing of the factor in LDS -- the recursion holds its share of K in registers (rs_recursion_reg), the items
+    // load their row of K and R~^-1 h_u from the HBM record themselves, after the recursion (one batch of one item per lane at a
+    // time: the register budget of two simulations per CU is 256).
+    template <bool AFFINE, bool SEG, bool KREG = false>
     MPC_PASS double fwd_resident()
     {
+        static_assert(!KREG || SEG, "register mode runs segment by segment");
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(ex.smem().n_hor);
-        const ResMap rm = SEG ? seg_map() : res_map();
+        const ResMap rm = KREG ? reg_map() : (SEG ? seg_map() : res_map());
         const int NSL = rm.T + 1;       // states the maps hold
-        double *X = rm.scr, *xch = X + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *xin = xs + RS_GROUPS * 12;
-        constexpr int R = rounds_for(6);
+        double *X = rm.scr, *xch = X + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *xin = xs + RS_GROUPS * 12, *psl = xin + 16;
+        constexpr int R = KREG ? 1 : rounds_for(6);
+        constexpr int NLD = KREG ? 29 : 16;    // KREG: + row j of K (12) and R~^-1 h_u [j]
         double *const G1 = ex.smem().w.G1, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
-        typename Ex::template PerLane<double> ld[R][16];
+        typename Ex::template PerLane<double> ld[R][NLD];
         typename Ex::template PerLane<double> r_al, r_a0, r_a1, r_a2;
         constexpr int RP = RS_ROUNDS;
         ex.wpar([&](int lane) { r_al.at(lane) = 1.0; r_a0.at(lane) = 0.0; r_a1.at(lane) = 0.0; r_a2.at(lane) = 0.0; });
@@ -1868,6 +2073,12 @@ struct Engine {
                             ld[r][8 * h + 4].at(lane) = gld(g3 + O_RD + c);   ld[r][8 * h + 5].at(lane) = gld(g3 + O_RD + 12 + c);
                             ld[r][8 * h + 6].at(lane) = gld(g3 + O_RM + c);   ld[r][8 * h + 7].at(lane) = gld(g3 + O_RM + 12 + c);
                         }
+                        if (KREG) {
+                            const double *g4 = G4 + (size_t)(kb + imin(kl, nt - 1)) * W4;
+#pragma unroll
+                            for (int i = 0; i < NX; i++) ld[r][16 + i].at(lane) = gld(g4 + O_K + j * 12 + i);
+                            ld[r][28].at(lane) = gld(g4 + O_VH + j);
+                        }
                     }
                 });
             };
@@ -1876,20 +2087,23 @@ struct Engine {
                 const int c0 = kb / rm.L, nc = (nt + rm.L - 1) / rm.L;
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
-                    copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
-                    copy_lanes<6, O_VH, W4, 6, true, NL>(rm.VH, G4, kb, kb + nt - 1, lane);
-                    copy_lanes<12, O_E, W4, 12, true, NL>(rm.E, G4, kb, kb + nt - 1, lane);
+                    if (!KREG) {
+                        copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
+                        copy_lanes<6, O_VH, W4, 6, true, NL>(rm.VH, G4, kb, kb + nt - 1, lane);
+                        copy_lanes<12, O_E, W4, 12, true, NL>(rm.E, G4, kb, kb + nt - 1, lane);
+                    }
                     if (!AFFINE) copy_lanes<12, O_PV, W4, 12, true, NL>(rm.P, G4, kb, kb + nsi - 1, lane);
                     copy_lanes<144, 0, 144, 144, true, NL>(rm.PHI, ex.smem().w.PH, c0, c0 + nc - 1, lane);
                 });
             }
-            issue(0);
+            if (!KREG) issue(0);
             PROF_T0(ts);
-            rs_recursion<true>(rm, X, xch, xs, nt, kb > 0 ? xin : nullptr);
+            if (KREG) rs_recursion_reg<true>(rm, X, xch, xs, psl, nt, kb, kb > 0 ? xin : nullptr);
+            else rs_recursion<true>(rm, X, xch, xs, nt, kb > 0 ? xin : nullptr);
             ex.barrier();
             PROF_ADD(PF_SEQ_FWD, ts);
             for (int base = 0; base < items; base += R * NT) {
-                if (base > 0) issue(base);
+                if (KREG || base > 0) issue(base);
                 ex.wpar([&](int lane) {
                     double al = r_al.at(lane), a0 = r_a0.at(lane), a1 = r_a1.at(lane), a2 = r_a2.at(lane);
                     auto side = [&](bool on, double sdv, double l, double t, double rd, double rmv, double &dt_o, double &dl_o) {
@@ -1904,11 +2118,18 @@ struct Engine {
                             double *g3 = G3 + (size_t)k * W3;
                             // du_k[j] = -(R~^-1 h_u + K dx_k)[j]  (stage N has no input: 0)
                             const int kc = imin(kl, nt - 1);
-                            const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)kc * 72 + j * 12);
                             const D2 *x2 = reinterpret_cast<const D2 *>(dxk);
-                            double s0 = rm.VH[(size_t)kc * 6 + j], s1 = 0.0;
+                            double s0, s1 = 0.0;
+                            if (KREG) {
+                                s0 = ld[r][NLD - 1].at(lane);
 #pragma unroll
-                            for (int i = 0; i < NX; i += 2) { const D2 kv = kr[i >> 1], xv = x2[i >> 1]; s0 += kv.x * xv.x; s1 += kv.y * xv.y; }
+                                for (int i = 0; i < NX; i += 2) { const D2 xv = x2[i >> 1]; s0 += ld[r][NLD - 13 + i].at(lane) * xv.x; s1 += ld[r][NLD - 12 + i].at(lane) * xv.y; }
+                            } else {
+                                const D2 *kr = reinterpret_cast<const D2 *>(rm.K + (size_t)kc * 72 + j * 12);
+                                s0 = rm.VH[(size_t)kc * 6 + j];
+#pragma unroll
+                                for (int i = 0; i < NX; i += 2) { const D2 kv = kr[i >> 1], xv = x2[i >> 1]; s0 += kv.x * xv.x; s1 += kv.y * xv.y; }
+                            }
                             const double du = k < Nl ? -(s0 + s1) : 0.0, dq = dxk[j];
                             if (!AFFINE) {
                                 gst(g3 + O_DW + j, du); gst(g3 + O_DW + 6 + j, dq); gst(g3 + O_DW + 12 + j, dxk[6 + j]);   // du_k, dx_k
@@ -1986,16 +2207,19 @@ struct Engine {
     //   items (stage, component): rm, rebuilt gt -> LDS ; c_k -> resident p array ; rs_recursion (p in place) ;
     //   items: h_u, R~^-1 h_u, e -> resident.  Only rm goes back to HBM.
     // SEG: segment by segment from the top of the horizon, p handed down; K comes from HBM, R~^-1 h_u | e | p go back there.
-    template <bool SEG>
+    // KREG: K columns for c_k and for the recursion come from the HBM record (items / registers); R~^-1 h_u and e go straight back to it.
+    template <bool SEG, bool KREG = false>
     MPC_PASS void corr_resident(double sigma_mu)
     {
+        static_assert(!KREG || SEG, "register mode runs segment by segment");
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
         const int Nl = ex.uni(ex.smem().n_hor);
-        const ResMap rm = SEG ? seg_map() : res_map();
+        const ResMap rm = KREG ? reg_map() : (SEG ? seg_map() : res_map());
         const int NSL = rm.T + 1;
-        double *GT = rm.scr, *RW = GT + (size_t)NSL * 18, *xch = RW + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *pin = xs + RS_GROUPS * 12;
+        double *GT = rm.scr, *RW = GT + (size_t)NSL * 18, *xch = RW + (size_t)NSL * 12, *xs = xch + RS_GROUPS * 12, *pin = xs + RS_GROUPS * 12,
+               *psl = pin + 16;
         constexpr int R = RS_ROUNDS;
         double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3, *const G4 = ex.smem().w.G4;
         typename Ex::template PerLane<double> ld[R][7];
@@ -2010,7 +2234,7 @@ struct Engine {
                 const int c0 = kb / rm.L, nc = (nt + rm.L - 1) / rm.L;
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
-                    copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
+                    if (!KREG) copy_lanes<72, O_K, W4, 72, true, NL>(rm.K, G4, kb, kb + nt - 1, lane);
                     copy_lanes<144, 0, 144, 144, true, NL>(rm.PHI, ex.smem().w.PH, c0, c0 + nc - 1, lane);
                 });
             }
@@ -2059,20 +2283,34 @@ struct Engine {
             ex.barrier();
             // ---- c_k = gt_x + A' w - Kfb' (gt_u + B' w) -> resident p array (stage N: p_N = gt_x; a lower segment's end state: p
             //      handed down from the segment above)
-            ex.wpar([&](int lane) {
-                for (int e = lane; e < items; e += NT) {
-                    const int kl = e / NX, j = e - kl * NX, k = kb + kl;
-                    const double *gt = GT + (size_t)kl * 18, *w = RW + (size_t)kl * 12, *kf = rm.K + (size_t)imin(kl, nt - 1) * 72;
-                    double vv = gt[6 + j];
-                    if (k < Nl) {
-                        vv += (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    double kc[R][6];     // column j of K_k: LDS (resident / segment) or, KREG, the HBM record
 #pragma unroll
-                        for (int m = 0; m < 6; m++) vv -= kf[m * 12 + j] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), kl = e / NX, j = e - kl * NX, kcl = imin(kl, nt - 1);
+#pragma unroll
+                        for (int m = 0; m < 6; m++)
+                            kc[r][m] = KREG ? gld(G4 + (size_t)(kb + kcl) * W4 + O_K + m * 12 + j) : rm.K[(size_t)kcl * 72 + m * 12 + j];
                     }
-                    rm.P[(size_t)kl * 12 + j] = vv;
-                }
-                if (SEG && !top && lane < NX) rm.P[(size_t)nt * 12 + lane] = pin[lane];
-            });
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int kl = e / NX, j = e - kl * NX, k = kb + kl;
+                            const double *gt = GT + (size_t)kl * 18, *w = RW + (size_t)kl * 12;
+                            double vv = gt[6 + j];
+                            if (k < Nl) {
+                                vv += (j < 6 ? w[j] : P.a12[j - 6] * w[j - 6] + P.a22[j - 6] * w[j]);
+#pragma unroll
+                                for (int m = 0; m < 6; m++) vv -= kc[r][m] * (gt[m] + P.b1[m] * w[m] + P.b2[m] * w[6 + m]);
+                            }
+                            rm.P[(size_t)kl * 12 + j] = vv;
+                        }
+                    }
+                    if (SEG && !top && base == 0 && lane < NX) rm.P[(size_t)nt * 12 + lane] = pin[lane];
+                });
+            }
             ex.barrier();
             // operands of the last phase (R~^-1 row, rb), issued before the recursion
             auto issue = [&](int base) {
@@ -2087,14 +2325,15 @@ struct Engine {
                     }
                 });
             };
-            issue(0);
+            if (!KREG) issue(0);
             PROF_T0(ts);
-            rs_recursion<false>(rm, rm.P, xch, xs, nt);
+            if (KREG) rs_recursion_reg<false>(rm, rm.P, xch, xs, psl, nt, kb);
+            else rs_recursion<false>(rm, rm.P, xch, xs, nt);
             ex.barrier();
             PROF_ADD(PF_SEQ_BWD, ts);
             // ---- h_u,k = gt_u + B'(p_{k+1} + w_k) ; R~^-1 h_u and e = rb - B R~^-1 h_u for the forward sweep
             for (int base = 0; base < items; base += R * NT) {
-                if (base > 0) issue(base);
+                if (KREG || base > 0) issue(base);
                 ex.wpar([&](int lane) {
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -2114,8 +2353,13 @@ struct Engine {
                                 vh = v0 + v1;
                                 ee = ld[r][6].at(lane) - (j < 6 ? P.b1[i6] : P.b2[i6]) * vh;
                             }
-                            if (j < 6) rm.VH[(size_t)kl * 6 + j] = vh;
-                            rm.E[(size_t)kl * 12 + j] = ee;
+                            if (KREG) {
+                                if (j < 6) gst(G4 + (size_t)k * W4 + O_VH + j, vh);
+                                gst(G4 + (size_t)k * W4 + O_E + j, ee);
+                            } else {
+                                if (j < 6) rm.VH[(size_t)kl * 6 + j] = vh;
+                                rm.E[(size_t)kl * 12 + j] = ee;
+                            }
                         }
                     }
                 });
@@ -2125,8 +2369,10 @@ struct Engine {
                 // what the final forward sweep reads of this segment goes back to the HBM record; p at its first stage goes down
                 copies([&](int lane, auto nl) {
                     constexpr int NL = decltype(nl)::value;
-                    copy_lanes<6, O_VH, W4, 6, false, NL>(rm.VH, G4, kb, kb + nsi - 1, lane);
-                    copy_lanes<12, O_E, W4, 12, false, NL>(rm.E, G4, kb, kb + nsi - 1, lane);
+                    if (!KREG) {
+                        copy_lanes<6, O_VH, W4, 6, false, NL>(rm.VH, G4, kb, kb + nsi - 1, lane);
+                        copy_lanes<12, O_E, W4, 12, false, NL>(rm.E, G4, kb, kb + nsi - 1, lane);
+                    }
                     copy_lanes<12, O_PV, W4, 12, false, NL>(rm.P, G4, kb, kb + nsi - 1, lane);
                     if (lane < NX) pin[lane] = rm.P[lane];
                 });
@@ -2143,7 +2389,11 @@ struct Engine {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
         const bool res = resident_ok();   // the horizon's factor fits the LDS pool: resident sweeps
-        const bool seg = segment_ok();    // it does not, but a segment of it does (whole pool of a CU): segment-resident sweeps
+        const bool reg = reg_ok();        // no room in LDS (half a pool, or a long horizon): the factor in registers / straight from HBM
+        const bool seg = !reg && segment_ok();    // a segment of the factor fits (whole pool of a CU): segment-resident sweeps
+#ifdef MPC_EMU_TRACE
+        { static int once = 0; if (!once) { once = 1; fprintf(stderr, "[emu] res %d reg %d seg %d pool %d\n", (int)res, (int)reg, (int)seg, (int)ex.smem().pool_n); } }
+#endif
         residual_direct(0, 0.0);
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
@@ -2167,6 +2417,9 @@ struct Engine {
             if (res) {
                 fact_pass_t<1>();
                 a_aff = has_bounds ? fwd_resident<true, false>() : fwd_resident<false, false>();
+            } else if (reg) {
+                fact_pass_t<2>();
+                a_aff = has_bounds ? fwd_resident<true, true, true>() : fwd_resident<false, true, true>();
             } else if (seg) {
                 fact_pass_t<2>();
                 a_aff = has_bounds ? fwd_resident<true, true>() : fwd_resident<false, true>();
@@ -2175,12 +2428,13 @@ struct Engine {
                 a_aff = has_bounds ? forward_step_pass<true>() : forward_step_pass<false>();
             }
             if (has_bounds) {
-                const bool rs = res || seg;
+                const bool rs = res || seg || reg;
                 const double S0 = rs ? ex.uni(sm.cen[1]) : ex.get1(sm.red[1]), S1 = rs ? ex.uni(sm.cen[2]) : ex.get1(sm.red[2]),
                              S2 = rs ? ex.uni(sm.cen[3]) : ex.get1(sm.red[3]);
                 const double mu_aff = (S0 + a_aff * (S1 + a_aff * S2)) / nc;
                 const double sigma = ipm::sigma(mu_aff, mu);
                 if (res) { corr_resident<false>(sigma * mu); alpha = fwd_resident<false, false>(); }
+                else if (reg) { corr_resident<true, true>(sigma * mu); alpha = fwd_resident<false, true, true>(); }
                 else if (seg) { corr_resident<true>(sigma * mu); alpha = fwd_resident<false, true>(); }
                 else { corrector_bwd_pass(sigma * mu); alpha = forward_step_pass<false>(); }
             } else {

@@ -724,6 +724,254 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
     return r;
 }
 
+// MODE 1 of the residual pass (the pass of every interior-point iteration but the first), ITEM-parallel: the residual pass has
+// no recursion in it -- every element is a function of its own stage's records and one row of each neighbour -- so instead of
+// walking the stages with a handful of lanes busy per role (residual_pass<1>: ~300 instructions per stage), the 64 lanes take
+// 64 ITEMS at a time, operands straight from the stage records in HBM / L2 into registers (mpc_core.h residual_direct, the same
+// three phases U | Y | S,D and the same arithmetic per element).  ~17 batches of loads per pass instead of 101 stages of chain;
+// while a batch is in flight the SIMD's other simulation runs.  y of every stage waits in the (idle) ring between Y and S.
+SE_DEV bool residual_items_ok(int N) { return (N + 1) * 6 <= RING_DOUBLES; }
+SE_PASS IpmNorms residual_items(double a)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor), NS = N + 1;
+    const SWs w = sm.w;
+    const int LD = uni(w.ld >> 3);
+    double *const G1 = w.G1, *const G2 = w.G2, *const G3 = w.G3;
+    double *const Y = sm.ring;                               // [NS][6], 5 used
+    auto gld = [](const double *p) { return *(MPC_GLOBAL const double *)p; };
+    auto gst = [](double *p, double v) { *(MPC_GLOBAL double *)p = v; };
+    double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
+    wait_vm<0>();                                            // no fetch of the sweep before is still landing in the ring
+    fence();
+    // ---------------------------------------------------------------- U: 16-byte items
+    {
+        // dw (18) | pi (12) += a * step: G1 [QW, QW + 30) <- G3 [DW, DW + 30); the step of multiplier k sits with stage k + 1
+        constexpr int IPS = 15, R = 8;
+        const int items = NS * IPS;
+        for (int base = 0; base < items; base += R * WAVE) {
+            D2 cur[R], stp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * LD + O_QW + c);
+                stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)(c >= 18 ? imin(k + 1, N) : k) * LD + O_DW + c);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / IPS, c = 2 * (e - k * IPS);
+                    const double aa = (c >= 18 && k >= N) ? 0.0 : a;   // no multiplier beyond the last dynamics
+                    D2 v = cur[r];
+                    v.x += aa * stp[r].x; v.y += aa * stp[r].y;
+                    *(MPC_GLOBAL D2 *)(G1 + (size_t)k * LD + O_QW + c) = v;
+                }
+            }
+        }
+    }
+    {
+        // lam (24) | t (24): G1 [QLAM, QLAM + 48) <- G3 [DLAM, DLAM + 48)
+        constexpr int IPS = 24, R = 8;
+        const int items = NS * IPS;
+        for (int base = 0; base < items; base += R * WAVE) {
+            D2 cur[R], stp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
+                cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * LD + O_QLAM + q);
+                stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)k * LD + O_DLAM + q);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / IPS, q = 2 * (e - k * IPS);
+                    const int sc = q >= 24 ? q - 24 : q, j = sc < 12 ? sc : sc - 12;        // side/component, component
+                    const bool ok = j < 6 ? k < N : (k >= 1 && k < N);                      // has_comp (same for j and j + 1)
+                    // which bound sides exist (|bound| >= 1e29 means absent, include/mpcbatch.h); sc < 12: lower, else upper
+                    const bool on0 = ok && (sc < 12 ? bnd_lo(P, j) > -BOUND_INF : bnd_hi(P, j) < BOUND_INF);
+                    const bool on1 = ok && (sc < 12 ? bnd_lo(P, j + 1) > -BOUND_INF : bnd_hi(P, j + 1) < BOUND_INF);
+                    D2 v = cur[r];
+                    v.x = ipm::step_floor(on0, v.x, a, stp[r].x); v.y = ipm::step_floor(on1, v.y, a, stp[r].y);
+                    *(MPC_GLOBAL D2 *)(G1 + (size_t)k * LD + O_QLAM + q) = v;
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+    fence();
+    // ---------------------------------------------------------------- Y: items (k < N, i < 5)
+    {
+        constexpr int R = 3;
+        const int items = N * NTASK;
+        for (int base = 0; base < items; base += R * WAVE) {
+            double g[R][12], d[R][12], rr[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / NTASK, i = e - k * NTASK;
+                const double *g1 = G1 + (size_t)k * LD + O_QW, *g2 = G2 + (size_t)k * LD;
+                rr[r] = gld(g2 + O_R + i);
+#pragma unroll
+                for (int j = 0; j < 6; j++) { g[r][j] = gld(g2 + O_GQ + i * 6 + j); d[r][j] = gld(g1 + 6 + j); }
+                // (row 4 alone has a velocity part; the other rows fetch it too -- all loads of the batch in flight before any branch)
+#pragma unroll
+                for (int j = 0; j < 6; j++) { g[r][6 + j] = gld(g2 + O_GV + j); d[r][6 + j] = gld(g1 + 12 + j); }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / NTASK, i = e - k * NTASK;
+                    double v = rr[r];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v += g[r][j] * d[r][j];
+                    if (i == 4) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) v += g[r][6 + j] * d[r][6 + j];
+                    }
+                    v *= P.w_task[i];
+                    Y[k * 6 + i] = v;
+                    gst(G2 + (size_t)k * LD + O_Y + i, v);
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+    fence();
+    // ---------------------------------------------------------------- S: joint items (k, j < 6): u_j, v_j, q_j ; D: dynamics items
+    {
+        constexpr int R = 2, RD = 2 * R;
+        const int items = NS * 6, items_d = NS * NX;
+        const double dt = P.dt, lm = P.lm;
+        // bound part of a bounded component ci: returns gt, updates rg, writes rd | rm | Gamma (an absent side holds lam = 0, t = 1)
+        auto bounds = [&](int k, int ci, double val_, double dv, double l_lo, double l_hi, double t_lo, double t_hi, double &rg) {
+            const bool hc = ci < 6 ? k < N : (k >= 1 && k < N);
+            const double b_lo = bnd_lo(P, ci), b_hi = bnd_hi(P, ci);
+            const bool blo = hc && b_lo > -BOUND_INF, bhi = hc && b_hi < BOUND_INF;
+            const double val = hc ? val_ : 0.0;
+            const double ll = blo ? l_lo : 0.0, lu = bhi ? l_hi : 0.0;
+            const double itl = fast_rcp(t_lo), itu = fast_rcp(t_hi);
+            const double rdl = blo ? dv - (b_lo - val) - t_lo : 0.0;
+            const double rdu = bhi ? (b_hi - val) - dv - t_hi : 0.0;
+            const double rml = ll * t_lo, rmu = lu * t_hi;
+            double gt = rg;
+            rg -= ll; gt -= ll;
+            double gam = ll * itl;
+            gt += (rml + ll * rdl) * itl;
+            rg += lu; gt += lu;
+            gam += lu * itu;
+            gt -= (rmu + lu * rdu) * itu;
+            a_mu += rml + rmu;
+            a_d = fmax(a_d, fmax(fabs(rdl), fabs(rdu)));
+            a_m = fmax(a_m, fmax(fabs(rml), fabs(rmu)));
+            double *g3 = G3 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD;
+            gst(g3 + O_RD + ci, rdl); gst(g3 + O_RD + 12 + ci, rdu);
+            gst(g3 + O_RM + ci, rml); gst(g3 + O_RM + 12 + ci, rmu);
+            gst(g2 + O_GAM + ci, gam);
+            return gt;
+        };
+        for (int base = 0; base < items; base += R * WAVE) {
+            double v[R][12], q[R][13], d[RD][5];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / 6, j = e - k * 6, km = imax(k - 1, 0);
+                const double *g1 = G1 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD, *gm = G1 + (size_t)km * LD;
+                v[r][0] = gld(g1 + O_U + j);      v[r][1] = gld(g1 + O_X + 6 + j);
+                v[r][2] = gld(g1 + O_QW + j);     v[r][3] = gld(g1 + O_QW + 12 + j);
+                v[r][4] = gld(g1 + O_QPI + j);    v[r][5] = gld(g1 + O_QPI + 6 + j);
+                v[r][6] = gld(gm + O_QPI + 6 + j);
+                v[r][7] = gld(g2 + O_GV + j);
+                v[r][8] = gld(g1 + O_QLAM + j);   v[r][9] = gld(g1 + O_QLAM + 12 + j);
+                v[r][10] = gld(g1 + O_QT + j);    v[r][11] = gld(g1 + O_QT + 12 + j);
+                q[r][0] = gld(g1 + O_X + j);  q[r][1] = gld(g1 + O_QW + 6 + j);
+#pragma unroll
+                for (int i = 0; i < NTASK; i++) q[r][2 + i] = gld(g2 + O_GQ + i * 6 + j);
+                q[r][7] = v[r][4]; q[r][8] = gld(gm + O_QPI + j);
+                q[r][9] = gld(g1 + O_QLAM + 6 + j);  q[r][10] = gld(g1 + O_QLAM + 18 + j);
+                q[r][11] = gld(g1 + O_QT + 6 + j);   q[r][12] = gld(g1 + O_QT + 18 + j);
+            }
+#pragma unroll
+            for (int r = 0; r < RD; r++) {
+                const int e = imin(2 * base + r * WAVE + lane, items_d - 1), k = e / NX, i = e - k * NX, kn = imin(k + 1, N);
+                const double *dw = G1 + (size_t)k * LD + O_QW;
+                d[r][0] = gld(dw + 6 + i);
+                d[r][1] = gld(dw + (i < 6 ? 12 + i : i - 6));
+                d[r][2] = gld(dw + (i < 6 ? i : i - 6));
+                d[r][3] = gld(G2 + (size_t)k * LD + O_BD + i);
+                d[r][4] = gld(G1 + (size_t)kn * LD + O_QW + 6 + i);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / 6, j = e - k * 6;
+                    const double du = v[r][2], dvv = v[r][3];
+                    const double uj = v[r][0] + du, vj = v[r][1] + dvv;
+                    const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+                    double *g3 = G3 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD;
+                    // u_j
+                    double rgu = 0.0;
+                    if (k < N) {
+                        rgu = dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
+                        rgu += P.b1[j] * v[r][4] + P.b2[j] * v[r][5];
+                        rgu += dt * lm * du;
+                    }
+                    const double gtu = bounds(k, j, v[r][0], du, v[r][8], v[r][9], v[r][10], v[r][11], rgu);
+                    gst(g3 + O_RG + j, rgu); gst(g2 + O_GT + j, gtu);
+                    // v_j: no bounds
+                    double rgv = 0.0;
+                    if (k >= 1) {
+                        if (k < N) {
+                            rgv = dt * (v[r][7] * Y[k * 6 + 4] + c2 * (vj - uj));
+                            rgv += P.a12[j] * v[r][4] + P.a22[j] * v[r][5];
+                        }
+                        rgv += (k < N ? dt : 1.0) * lm * dvv;
+                        rgv -= v[r][6];
+                    }
+                    gst(g3 + O_RG + 12 + j, rgv); gst(g2 + O_GT + 12 + j, rgv);
+                    // q_j; pi_k[j] is v[r][4]
+                    const double dq = q[r][1];
+                    double rg = 0.0;
+                    if (k >= 1) {
+                        if (k < N) {
+                            double s_ = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NTASK; i++) s_ += q[r][2 + i] * Y[k * 6 + i];
+                            rg = dt * s_ + q[r][7];
+                        }
+                        rg += (k < N ? dt : 1.0) * lm * dq;
+                        rg -= q[r][8];
+                    }
+                    const double gt = bounds(k, 6 + j, q[r][0], dq, q[r][9], q[r][10], q[r][11], q[r][12], rg);
+                    gst(g3 + O_RG + 6 + j, rg); gst(g2 + O_GT + 6 + j, gt);
+                    a_g = fmax(a_g, fmax(fmax(fabs(rgu), fabs(rgv)), fabs(rg)));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RD; r++) {
+                const int e = 2 * base + r * WAVE + lane;
+                if (e < items_d && e < 2 * (base + R * WAVE)) {
+                    const int k = e / NX, i = e - k * NX;
+                    double vv = 0.0;
+                    if (k < N) {
+                        if (i < 6) vv = d[r][0] + P.a12[i] * d[r][1] + P.b1[i] * d[r][2];
+                        else vv = P.a22[i - 6] * d[r][0] + P.b2[i - 6] * d[r][1];
+                        vv += d[r][3] - d[r][4];
+                        a_b = fmax(a_b, fabs(vv));
+                    }
+                    gst(G2 + (size_t)k * LD + O_RB + i, vv);
+                }
+            }
+        }
+    }
+    IpmNorms r;
+    r.ng = wmax(a_g); r.nb = wmax(a_b); r.nd = wmax(a_d); r.nm = wmax(a_m); r.smu = wsum(a_mu); r.nc = 0.0;
+    return r;
+}
+
 // =============================================================================================== factorisation sweep
 // Backward Riccati sweep, matrix AND vector recursion of a stage in the same two phases (mpc_core.h fact_pass):
 //   lanes 0..35  block (a,b) of the 12x12 cost-to-go in registers for the whole sweep
@@ -1289,7 +1537,11 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr
         }
         const double a = ipm::step_scale(alpha);
         SPROF_T0(tr);
+#ifdef MPCB_STREAM_SEQ_RES
         r = residual_pass<1>(a);
+#else
+        r = residual_items_ok(uni(sm.n_hor)) ? residual_items(a) : residual_pass<1>(a);
+#endif
         SPROF_ADD(4, tr);
         mu = nc > 0 ? unid(r.smu) / nc : 0.0;
     }

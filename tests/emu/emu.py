@@ -6,7 +6,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libmpc_emu.so")
+# MPC_EMU_DEFINES="-DMPCB_REG_MODE=2 ..." builds (and loads) a variant of the engine next to the default one
+_DEFINES = os.environ.get("MPC_EMU_DEFINES", "").split()
+_LIB = os.path.join(_HERE, "libmpc_emu%s.so" % ("_" + "".join(c if c.isalnum() else "_" for c in "".join(_DEFINES)) if _DEFINES else ""))
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "robotic_mpc_amd", "csrc")
 
 
@@ -17,7 +19,7 @@ class Problem(C.Structure):
 def build(force=False):
     srcs = [os.path.join(_HERE, "emu_harness.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["hipcc", "-x", "hip", "--offload-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+        subprocess.check_call(["hipcc", "-x", "hip", "--offload-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", *_DEFINES,
                                "-o", _LIB, os.path.join(_HERE, "emu_harness.cpp")])
     return _LIB
 

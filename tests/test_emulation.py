@@ -31,7 +31,9 @@ def _cfg(**kw):
     (65, 0.2, "SQP_RTI", 7, 0, 4), (130, 0.05, "SQP_RTI", 0, 0, 4), (23, 0.3, "SQP_RTI", 0, 2048, 4),
     (11, 0.2, "SQP", 3, 2048, 1), (100, 0.05, "SQP_RTI", 0, 4096, 2), (30, 0.1, "SQP", 0, 0, 8), (5, 0.05, "SQP_RTI", 0, 4096, 4), (2, 0.05, "SQP", 0, 2048, 1),
     # horizons beyond the LDS-resident limit with the whole pool: SEGMENT-resident sweeps (2 and 3 segments, a segment of exactly SEG_T)
-    (224, 0.04, "SQP_RTI", 0, 0, 8), (300, 0.03, "SQP_RTI", 0, 0, 4), (126, 0.04, "SQP", 0, 0, 4)])
+    (224, 0.04, "SQP_RTI", 0, 0, 8), (300, 0.03, "SQP_RTI", 0, 0, 4), (126, 0.04, "SQP", 0, 0, 4),
+    # half a CU's pool (two simulations per CU on the device), four wavefronts: one and two segments of the register-resident sweeps
+    (100, 0.05, "SQP_RTI", 0, 9156, 4), (130, 0.03, "SQP", 0, 9156, 4), (7, 0.05, "SQP", 0, 9156, 4)])
 def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk, pool, waves):
     import emu
 

@@ -294,16 +294,16 @@ def test_solver_failures_are_data_and_match_the_oracle(eng, orc, ur10, ur10_rb, 
 
 @pytest.mark.parametrize("N,T", [(100, 0.5), (200, 0.3), (300, 0.15)])
 def test_resident_segment_and_streaming_sweeps_agree(orc, ur10, ur10_rb, monkeypatch, N, T):
-    """Round 3: the latency engine has three sweep implementations behind one launch -- the factor LDS-resident with
-    chunk-parallel recursions (N <= ~125, a whole CU's pool), the same one 112-transition SEGMENT at a time (longer
-    horizons), and the streaming sweeps (half a pool: two simulations per CU).  The same simulations through the default
-    geometry (resident at N = 100, segments at N = 200 / 300) and through MPCB_SIMS_PER_CU=2 (streaming): identical solver
-    decisions at every step, trajectories within 1e-11 of each other, both within 1e-9 of the oracle."""
+    """Round 3: the latency engine has three chunk-parallel sweep implementations behind one launch -- the factor LDS-resident
+    (N <= ~125, a whole CU's pool), the same one 112-transition SEGMENT at a time (longer horizons), and, with half a pool
+    (two simulations per CU), the factor in REGISTERS / straight from its HBM record (rs_recursion_reg).  The same simulations
+    through the default geometry (resident at N = 100, segments at N = 200 / 300) and through MPCB_SIMS_PER_CU=2 (register
+    sweeps): identical solver decisions at every step, trajectories within 1e-11 of each other, both within 1e-9 of the oracle."""
     from robotic_mpc_amd import engine
 
     cfgs = _jitter(5, seed=7 * N, prediction_horizon=N, simulation_time=T)
     outs = {}
-    for name, env in (("default", {}), ("streaming", {"MPCB_SIMS_PER_CU": "2"})):
+    for name, env in (("default", {}), ("half_pool", {"MPCB_SIMS_PER_CU": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = engine.MpcBatchEngine(0)
@@ -312,7 +312,7 @@ def test_resident_segment_and_streaming_sweeps_agree(orc, ur10, ur10_rb, monkeyp
         e.close()
         assert geo["engine"] == 0
         assert (geo["pool_bytes"] > 100000) == (name == "default"), geo
-    a, b = outs["default"], outs["streaming"]
+    a, b = outs["default"], outs["half_pool"]
     for k in ("status", "sqp_iter", "qp_iter"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     for k in ("z", "u", "ee_pose", "errors"):

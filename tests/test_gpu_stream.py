@@ -324,7 +324,7 @@ def test_work_queue_waits_for_a_legitimately_slow_simulation(monkeypatch, ur10):
     from robotic_mpc_amd import engine
 
     monkeypatch.setenv("MPCB_ENGINE", "stream")
-    so = {"nlp_solver_type": "SQP", "nlp_solver_max_iter": 12, "qp_solver_iter_max": 50}
+    so = {"nlp_solver_type": "SQP", "nlp_solver_max_iter": 12, "qp_solver_iter_max": 150}
     cfgs = _jitter(5, seed=21, prediction_horizon=40, simulation_time=0.24, solver_options=so)
     slow = _cfg(prediction_horizon=40, simulation_time=0.24, solver_options=so,
                 qdot_min=np.full(6, -0.02), qdot_max=np.full(6, 0.02), q_min=np.full(6, -0.5), q_max=np.full(6, 0.5))
@@ -339,7 +339,10 @@ def test_work_queue_waits_for_a_legitimately_slow_simulation(monkeypatch, ur10):
     for k in runs[0]:
         if k not in ("solver_time", "plant_time"):
             np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
-    assert runs[0]["qp_iter"][0].sum() > 1.5 * runs[0]["qp_iter"][1:].sum(axis=1).max()   # it IS slower than the others (its chunks are waited for)
+    # it IS slower than the others (its chunks are waited for); how much depends on the path its failing QPs take -- failed steps
+    # are path-dependent by nature (oracle, latency and throughput engine each take another one), so only the order is asserted
+    assert (runs[0]["status"][0] != 0).any() and (runs[0]["status"][1:] == 0).all()
+    assert runs[0]["qp_iter"][0].sum() > 1.2 * runs[0]["qp_iter"][1:].sum(axis=1).max()
     monkeypatch.setenv("MPCB_QUEUE_TIMEOUT_S", "1e-7")
     e = engine.MpcBatchEngine(0)
     with pytest.raises(engine.EngineError, match="hand-off"):
