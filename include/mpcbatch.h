@@ -51,19 +51,22 @@ extern "C" {
                                           residuals, right-hand sides, steps and all outputs stay fp64
                                           (BASELINE.json configs[4]; SQP_RTI on the throughput engine only)     */
 
-/* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 2-4
- * wavefronts and most of a CU's LDS per simulation; batches up to a few simulations per CU, and every SQP run) and
+/* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 4-8
+ * wavefronts and half or all of a CU's LDS per simulation; batches up to a few simulations per CU, and most SQP runs) and
  * the THROUGHPUT engine (one wavefront per simulation, records streamed; SQP_RTI batches of >= MPCB_STREAM_MIN_BATCH
- * simulations, full-SQP batches of >= MPCB_STREAM_MIN_BATCH_SQP simulations running >= 100 steps, every fp32-Riccati run,
- * every ragged batch).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
+ * simulations, full-SQP batches of >= MPCB_STREAM_MIN_BATCH_SQP simulations running >= MPCB_STREAM_MIN_STEPS_SQP steps,
+ * every fp32-Riccati run, every ragged batch).  mpcb_setup picks; the environment variable MPCB_ENGINE=latency|stream
  * overrides the choice where both apply.  An SQP_RTI bucket of at least as many simulations as the GPU holds wavefronts of
  * the throughput engine (8 per CU) is launched as a work queue over (simulation, MPCB_STREAM_CHUNK = 10 closed-loop steps)
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
  * within a bound derived from the work limit of one chunk -- 4 x chunk steps x SQP iterations x QP iterations x (N+1) x 20 us
  * + 30 s; MPCB_QUEUE_TIMEOUT_S overrides it -- is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
-#define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on, for runs of >= 100 closed-loop steps */
-#define MPCB_STREAM_MIN_BATCH 1408   /* measured crossover at N=100, 600 steps, one MI355X (profiles/r03_engine_sweep.txt): 1280 simulations
-                                        741 k (latency engine, two per CU) vs 720 k, 1536: ~745 k vs 826 k steps/s */
+/* Measured crossovers, N=100, one MI355X (profiles/r03_engine_sweep.txt; latency engine two simulations per CU vs throughput
+ * engine, steps/s).  Full SQP, 600 steps: 2560 simulations 256 k vs 229 k, 3072: 265 k vs 265 k, 4096: 289 k vs 321 k;
+ * 4096 x 100 steps: 80 k vs 72 k.  SQP_RTI, 600 steps: 1280 simulations 862 k vs 808 k, 1536: 901 k vs 933 k. */
+#define MPCB_STREAM_MIN_BATCH_SQP 3328   /* full SQP: from this many simulations on ... */
+#define MPCB_STREAM_MIN_STEPS_SQP 300    /* ... for runs of at least this many closed-loop steps */
+#define MPCB_STREAM_MIN_BATCH 1408
 
 typedef struct mpcb_handle mpcb_handle;
 
@@ -159,6 +162,8 @@ int mpcb_kernel_info(mpcb_handle *h, int *vgprs, int *sgprs, int *lds_bytes, int
 
 /* Kernel family mpcb_setup chose for the current problem: 0 latency engine, 1 throughput engine (< 0: error). */
 int mpcb_engine(mpcb_handle *h);
+/* The family mpcb_setup WOULD choose for a uniform (not ragged) problem of this shape: host logic only, no device touched. */
+int mpcb_engine_for(const mpcb_problem *p);
 
 /* Launch geometry chosen by mpcb_setup for the current batch: wavefronts cooperating on one
  * simulation (one workgroup per simulation), and the dynamic-LDS chunk pool per workgroup. */

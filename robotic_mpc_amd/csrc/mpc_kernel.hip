@@ -519,11 +519,12 @@ static int pick_engine(const mpcb_problem *p, bool ragged = false)
     // Full SQP work per step is heavy-tailed while the closed loop settles (a few simulations run into
     // nlp_solver_max_iter): short or small runs end with those simulations' sequential chains, where the latency engine is
     // faster per simulation; long runs of large batches are throughput work again, and the work-queue launch balances them.
-    // Measured at N = 100 (profiles/r02_sqp_sweep.txt), throughput engine queued / latency engine, steps/s: batch 4096 x 600
-    // steps 299 k / 214 k, x 100 steps 67 k / 59 k, x 50 steps 34 k / 42 k; batch 3072 x 600: 245 k / 195 k; 2048 x 600: 179 k / 194 k.
+    // Measured at N = 100 (profiles/r03_engine_sweep.txt), throughput engine queued / latency engine (two simulations per CU,
+    // register-resident sweeps), steps/s: batch 4096 x 600 steps 321 k / 289 k, x 100 steps 72 k / 80 k; batch 3072 x 600:
+    // 265 k / 265 k; 2560 x 600: 229 k / 256 k.  (Round 2, before those sweeps: 299 k / 214 k, 67 k / 59 k, 245 k / 195 k.)
     int e = 0;
     if (p->solver_type == MPCB_SOLVER_SQP_RTI) e = p->batch >= MPCB_STREAM_MIN_BATCH ? 1 : 0;
-    else e = p->batch >= MPCB_STREAM_MIN_BATCH_SQP && p->Nsim >= 100 ? 1 : 0;
+    else e = p->batch >= MPCB_STREAM_MIN_BATCH_SQP && p->Nsim >= MPCB_STREAM_MIN_STEPS_SQP ? 1 : 0;
     if (const char *env = getenv("MPCB_ENGINE")) {
         if (!strcmp(env, "stream")) e = 1;
         else if (!strcmp(env, "latency")) e = 0;
@@ -783,6 +784,12 @@ int mpcb_engine(mpcb_handle *h)
 {
     if (!h || !h->ready) return MPCB_EINVAL;
     return h->engine;
+}
+
+int mpcb_engine_for(const mpcb_problem *p)
+{
+    if (!p || p->N < 1 || p->batch < 1) return MPCB_EINVAL;
+    return pick_engine(p);
 }
 
 int mpcb_launch_info(mpcb_handle *h, int *waves_per_sim, int *pool_bytes)

@@ -739,10 +739,16 @@ SE_PASS IpmNorms residual_items(double a)
     const int N = uni(sm.n_hor), NS = N + 1;
     const SWs w = sm.w;
     const int LD = uni(w.ld >> 3);
-    double *const G1 = w.G1, *const G2 = w.G2, *const G3 = w.G3;
+    // ONE record per stage, [G1 | G2 | G3 | G4]: every field of a stage is a constant offset from the stage's base, so an item
+    // forms one address (base + stage * LD + its lane-dependent column) and all its loads and stores use immediate offsets
+    // (uniform 64-bit base + 32-bit byte offset in a register + immediate: the addressing mode of global_load / global_store)
+    MPC_GLOBAL char *const gb = (MPC_GLOBAL char *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)w.G1 >> 32)) << 32) |
+                                                    (unsigned)uni((int)(unsigned long long)w.G1));
+    auto rec = [&](int k, int col) { return (MPC_GLOBAL double *)(gb + (unsigned)((k * LD + col) << 3)); };
+    constexpr int C2 = W1, C3 = W1 + W2;                      // G2, G3 columns inside the record
     double *const Y = sm.ring;                               // [NS][6], 5 used
-    auto gld = [](const double *p) { return *(MPC_GLOBAL const double *)p; };
-    auto gst = [](double *p, double v) { *(MPC_GLOBAL double *)p = v; };
+    auto gld = [](const MPC_GLOBAL double *p) { return *p; };
+    auto gst = [](MPC_GLOBAL double *p, double v) { *p = v; };
     double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0;
     wait_vm<0>();                                            // no fetch of the sweep before is still landing in the ring
     fence();
@@ -756,8 +762,8 @@ SE_PASS IpmNorms residual_items(double a)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
-                cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * LD + O_QW + c);
-                stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)(c >= 18 ? imin(k + 1, N) : k) * LD + O_DW + c);
+                cur[r] = *(MPC_GLOBAL const D2 *)(rec(k, c) + O_QW);
+                stp[r] = *(MPC_GLOBAL const D2 *)(rec(c >= 18 ? imin(k + 1, N) : k, c) + C3 + O_DW);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -767,7 +773,7 @@ SE_PASS IpmNorms residual_items(double a)
                     const double aa = (c >= 18 && k >= N) ? 0.0 : a;   // no multiplier beyond the last dynamics
                     D2 v = cur[r];
                     v.x += aa * stp[r].x; v.y += aa * stp[r].y;
-                    *(MPC_GLOBAL D2 *)(G1 + (size_t)k * LD + O_QW + c) = v;
+                    *(MPC_GLOBAL D2 *)(rec(k, c) + O_QW) = v;
                 }
             }
         }
@@ -781,8 +787,8 @@ SE_PASS IpmNorms residual_items(double a)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
-                cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * LD + O_QLAM + q);
-                stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)k * LD + O_DLAM + q);
+                cur[r] = *(MPC_GLOBAL const D2 *)(rec(k, q) + O_QLAM);
+                stp[r] = *(MPC_GLOBAL const D2 *)(rec(k, q) + C3 + O_DLAM);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -796,7 +802,7 @@ SE_PASS IpmNorms residual_items(double a)
                     const bool on1 = ok && (sc < 12 ? bnd_lo(P, j + 1) > -BOUND_INF : bnd_hi(P, j + 1) < BOUND_INF);
                     D2 v = cur[r];
                     v.x = ipm::step_floor(on0, v.x, a, stp[r].x); v.y = ipm::step_floor(on1, v.y, a, stp[r].y);
-                    *(MPC_GLOBAL D2 *)(G1 + (size_t)k * LD + O_QLAM + q) = v;
+                    *(MPC_GLOBAL D2 *)(rec(k, q) + O_QLAM) = v;
                 }
             }
         }
@@ -812,13 +818,13 @@ SE_PASS IpmNorms residual_items(double a)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = imin(base + r * WAVE + lane, items - 1), k = e / NTASK, i = e - k * NTASK;
-                const double *g1 = G1 + (size_t)k * LD + O_QW, *g2 = G2 + (size_t)k * LD;
-                rr[r] = gld(g2 + O_R + i);
+                const MPC_GLOBAL double *g1 = rec(k, 0) + O_QW, *g2 = rec(k, i) + C2, *gq = rec(k, i * 6) + C2;
+                rr[r] = gld(g2 + O_R);
 #pragma unroll
-                for (int j = 0; j < 6; j++) { g[r][j] = gld(g2 + O_GQ + i * 6 + j); d[r][j] = gld(g1 + 6 + j); }
+                for (int j = 0; j < 6; j++) { g[r][j] = gld(gq + O_GQ + j); d[r][j] = gld(g1 + 6 + j); }
                 // (row 4 alone has a velocity part; the other rows fetch it too -- all loads of the batch in flight before any branch)
 #pragma unroll
-                for (int j = 0; j < 6; j++) { g[r][6 + j] = gld(g2 + O_GV + j); d[r][6 + j] = gld(g1 + 12 + j); }
+                for (int j = 0; j < 6; j++) { g[r][6 + j] = gld(g1 - O_QW + C2 + O_GV + j); d[r][6 + j] = gld(g1 + 12 + j); }
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -834,7 +840,7 @@ SE_PASS IpmNorms residual_items(double a)
                     }
                     v *= P.w_task[i];
                     Y[k * 6 + i] = v;
-                    gst(G2 + (size_t)k * LD + O_Y + i, v);
+                    gst(rec(k, i) + C2 + O_Y, v);
                 }
             }
         }
@@ -867,10 +873,10 @@ SE_PASS IpmNorms residual_items(double a)
             a_mu += rml + rmu;
             a_d = fmax(a_d, fmax(fabs(rdl), fabs(rdu)));
             a_m = fmax(a_m, fmax(fabs(rml), fabs(rmu)));
-            double *g3 = G3 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD;
-            gst(g3 + O_RD + ci, rdl); gst(g3 + O_RD + 12 + ci, rdu);
-            gst(g3 + O_RM + ci, rml); gst(g3 + O_RM + 12 + ci, rmu);
-            gst(g2 + O_GAM + ci, gam);
+            MPC_GLOBAL double *rc = rec(k, ci);
+            gst(rc + C3 + O_RD, rdl); gst(rc + C3 + O_RD + 12, rdu);
+            gst(rc + C3 + O_RM, rml); gst(rc + C3 + O_RM + 12, rmu);
+            gst(rc + C2 + O_GAM, gam);
             return gt;
         };
         for (int base = 0; base < items; base += R * WAVE) {
@@ -878,30 +884,30 @@ SE_PASS IpmNorms residual_items(double a)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = imin(base + r * WAVE + lane, items - 1), k = e / 6, j = e - k * 6, km = imax(k - 1, 0);
-                const double *g1 = G1 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD, *gm = G1 + (size_t)km * LD;
-                v[r][0] = gld(g1 + O_U + j);      v[r][1] = gld(g1 + O_X + 6 + j);
-                v[r][2] = gld(g1 + O_QW + j);     v[r][3] = gld(g1 + O_QW + 12 + j);
-                v[r][4] = gld(g1 + O_QPI + j);    v[r][5] = gld(g1 + O_QPI + 6 + j);
-                v[r][6] = gld(gm + O_QPI + 6 + j);
-                v[r][7] = gld(g2 + O_GV + j);
-                v[r][8] = gld(g1 + O_QLAM + j);   v[r][9] = gld(g1 + O_QLAM + 12 + j);
-                v[r][10] = gld(g1 + O_QT + j);    v[r][11] = gld(g1 + O_QT + 12 + j);
-                q[r][0] = gld(g1 + O_X + j);  q[r][1] = gld(g1 + O_QW + 6 + j);
+                const MPC_GLOBAL double *g1 = rec(k, j), *g2 = g1 + C2, *gm = rec(km, j);
+                v[r][0] = gld(g1 + O_U);      v[r][1] = gld(g1 + O_X + 6);
+                v[r][2] = gld(g1 + O_QW);     v[r][3] = gld(g1 + O_QW + 12);
+                v[r][4] = gld(g1 + O_QPI);    v[r][5] = gld(g1 + O_QPI + 6);
+                v[r][6] = gld(gm + O_QPI + 6);
+                v[r][7] = gld(g2 + O_GV);
+                v[r][8] = gld(g1 + O_QLAM);   v[r][9] = gld(g1 + O_QLAM + 12);
+                v[r][10] = gld(g1 + O_QT);    v[r][11] = gld(g1 + O_QT + 12);
+                q[r][0] = gld(g1 + O_X);  q[r][1] = gld(g1 + O_QW + 6);
 #pragma unroll
-                for (int i = 0; i < NTASK; i++) q[r][2 + i] = gld(g2 + O_GQ + i * 6 + j);
-                q[r][7] = v[r][4]; q[r][8] = gld(gm + O_QPI + j);
-                q[r][9] = gld(g1 + O_QLAM + 6 + j);  q[r][10] = gld(g1 + O_QLAM + 18 + j);
-                q[r][11] = gld(g1 + O_QT + 6 + j);   q[r][12] = gld(g1 + O_QT + 18 + j);
+                for (int i = 0; i < NTASK; i++) q[r][2 + i] = gld(g2 + O_GQ + i * 6);
+                q[r][7] = v[r][4]; q[r][8] = gld(gm + O_QPI);
+                q[r][9] = gld(g1 + O_QLAM + 6);  q[r][10] = gld(g1 + O_QLAM + 18);
+                q[r][11] = gld(g1 + O_QT + 6);   q[r][12] = gld(g1 + O_QT + 18);
             }
 #pragma unroll
             for (int r = 0; r < RD; r++) {
                 const int e = imin(2 * base + r * WAVE + lane, items_d - 1), k = e / NX, i = e - k * NX, kn = imin(k + 1, N);
-                const double *dw = G1 + (size_t)k * LD + O_QW;
-                d[r][0] = gld(dw + 6 + i);
-                d[r][1] = gld(dw + (i < 6 ? 12 + i : i - 6));
-                d[r][2] = gld(dw + (i < 6 ? i : i - 6));
-                d[r][3] = gld(G2 + (size_t)k * LD + O_BD + i);
-                d[r][4] = gld(G1 + (size_t)kn * LD + O_QW + 6 + i);
+                const MPC_GLOBAL double *ri = rec(k, i), *r6 = rec(k, i < 6 ? i : i - 6);
+                d[r][0] = gld(ri + O_QW + 6);
+                d[r][1] = gld(i < 6 ? r6 + O_QW + 12 : r6 + O_QW);     // dv_i | du_(i-6)
+                d[r][2] = gld(r6 + O_QW);
+                d[r][3] = gld(ri + C2 + O_BD);
+                d[r][4] = gld(rec(kn, i) + O_QW + 6);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -911,7 +917,7 @@ SE_PASS IpmNorms residual_items(double a)
                     const double du = v[r][2], dvv = v[r][3];
                     const double uj = v[r][0] + du, vj = v[r][1] + dvv;
                     const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
-                    double *g3 = G3 + (size_t)k * LD, *g2 = G2 + (size_t)k * LD;
+                    MPC_GLOBAL double *g3 = rec(k, j) + C3, *g2 = rec(k, j) + C2;
                     // u_j
                     double rgu = 0.0;
                     if (k < N) {
@@ -920,7 +926,7 @@ SE_PASS IpmNorms residual_items(double a)
                         rgu += dt * lm * du;
                     }
                     const double gtu = bounds(k, j, v[r][0], du, v[r][8], v[r][9], v[r][10], v[r][11], rgu);
-                    gst(g3 + O_RG + j, rgu); gst(g2 + O_GT + j, gtu);
+                    gst(g3 + O_RG, rgu); gst(g2 + O_GT, gtu);
                     // v_j: no bounds
                     double rgv = 0.0;
                     if (k >= 1) {
@@ -931,7 +937,7 @@ SE_PASS IpmNorms residual_items(double a)
                         rgv += (k < N ? dt : 1.0) * lm * dvv;
                         rgv -= v[r][6];
                     }
-                    gst(g3 + O_RG + 12 + j, rgv); gst(g2 + O_GT + 12 + j, rgv);
+                    gst(g3 + O_RG + 12, rgv); gst(g2 + O_GT + 12, rgv);
                     // q_j; pi_k[j] is v[r][4]
                     const double dq = q[r][1];
                     double rg = 0.0;
@@ -946,7 +952,7 @@ SE_PASS IpmNorms residual_items(double a)
                         rg -= q[r][8];
                     }
                     const double gt = bounds(k, 6 + j, q[r][0], dq, q[r][9], q[r][10], q[r][11], q[r][12], rg);
-                    gst(g3 + O_RG + 6 + j, rg); gst(g2 + O_GT + 6 + j, gt);
+                    gst(g3 + O_RG + 6, rg); gst(g2 + O_GT + 6, gt);
                     a_g = fmax(a_g, fmax(fmax(fabs(rgu), fabs(rgv)), fabs(rg)));
                 }
             }
@@ -962,7 +968,7 @@ SE_PASS IpmNorms residual_items(double a)
                         vv += d[r][3] - d[r][4];
                         a_b = fmax(a_b, fabs(vv));
                     }
-                    gst(G2 + (size_t)k * LD + O_RB + i, vv);
+                    gst(rec(k, i) + C2 + O_RB, vv);
                 }
             }
         }

@@ -58,7 +58,8 @@ class EngineError(RuntimeError):
 
 _EXPORTS = ("mpcb_version", "mpcb_device_count", "mpcb_create", "mpcb_destroy", "mpcb_last_error",
             "mpcb_workspace_bytes", "mpcb_result_bytes_per_sim", "mpcb_setup", "mpcb_rollout", "mpcb_sync",
-            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_engine", "mpcb_summary", "mpcb_run")
+            "mpcb_last_kernel_ms", "mpcb_kernel_info", "mpcb_launch_info", "mpcb_engine", "mpcb_engine_for", "mpcb_summary",
+            "mpcb_run")
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -84,6 +85,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.mpcb_destroy.restype = None
     lib.mpcb_last_error.argtypes = [C.c_void_p]
     lib.mpcb_last_error.restype = C.c_char_p
+    lib.mpcb_engine_for.argtypes = [C.POINTER(MpcbProblem)]
+    lib.mpcb_engine_for.restype = C.c_int
     lib.mpcb_workspace_bytes.argtypes = [C.POINTER(MpcbProblem)]
     lib.mpcb_workspace_bytes.restype = C.c_size_t
     lib.mpcb_result_bytes_per_sim.argtypes = [C.POINTER(MpcbProblem)]
@@ -113,6 +116,14 @@ def make_problem(cfgs: Sequence[Dict]) -> MpcbProblem:
             raise ValueError("all simulations of one launch must share Nsim, solver options and robot (and N, except SQP_RTI)")
     return MpcbProblem(len(cfgs), max(c["N"] for c in cfgs), c0["Nsim"], c0["solver_type"], c0["max_iter"], c0["qp_iter_max"],
                        int(c0["fixed_step"]), int(c0.get("precision", 0)))
+
+
+def engine_for(batch: int, N: int, Nsim: int, solver: str = "SQP_RTI", precision: int = 0, lib: Optional[C.CDLL] = None) -> int:
+    """Kernel family a uniform bucket of this shape is sent to (mpcb_engine_for; host logic, no GPU needed):
+    0 latency engine, 1 throughput engine."""
+    lib = lib or load_library()
+    pb = MpcbProblem(batch, N, Nsim, 0 if solver == "SQP" else 1, 100, 50, 0, precision)
+    return int(lib.mpcb_engine_for(C.byref(pb)))
 
 
 class MpcBatchEngine:

@@ -155,11 +155,18 @@ def test_config3_full_sqp_batch512_matches_oracle(eng, orc, ur10, ur10_rb):
             np.testing.assert_allclose(out[k][i][:, :n + 1], ref[k][:, :n + 1], atol=ATOL, rtol=0, err_msg=f"sim {i} {k}")
 
 
-def test_config3_full_sqp_large_batch_takes_the_work_queue_and_matches_oracle(eng, orc, ur10, ur10_rb):
-    """BASELINE configs[3] at a size where full SQP is throughput work: 2560 simulations (>= MPCB_STREAM_MIN_BATCH_SQP),
-    100 closed-loop steps -> throughput engine, work-queue launch (no env overrides).  Same random coefficients as the
-    batch-512 test; spot checks against the oracle with strict parity up to the first flagged step."""
-    from robotic_mpc_amd import config
+def test_config3_full_sqp_large_batch_takes_the_work_queue_and_matches_oracle(orc, ur10, ur10_rb, monkeypatch):
+    """BASELINE configs[3], 2560 full-SQP simulations over all 600 closed-loop steps on the THROUGHPUT engine's work-queue
+    launch.  (Since the latency engine's register-resident sweeps this size is no longer sent there by default -- full SQP goes
+    to the throughput engine from MPCB_STREAM_MIN_BATCH_SQP = 3328 simulations x >= 300 steps -- so the engine is named here;
+    the default pick at both sides of that threshold is asserted first.)  Same random coefficients as the batch-512 test; spot
+    checks against the oracle with strict parity up to the first flagged step."""
+    from robotic_mpc_amd import config, engine
+
+    for n, steps, want in ((2560, 600, 0), (3328, 600, 1), (4096, 100, 0)):
+        assert engine.engine_for(n, 100, steps, "SQP") == want, (n, steps)
+    monkeypatch.setenv("MPCB_ENGINE", "stream")
+    eng = engine.MpcBatchEngine(0)
 
     rng_c, rng_r = np.random.default_rng(2), np.random.default_rng(1)
     base = dict(a=-0.1, b=0.1, c=-0.01, d=0.01, e=0.01, f=0.0)
