@@ -1,5 +1,6 @@
-// What is the shader clock under a latency-bound launch?  One wavefront per CU runs a loop of s_nop 15 (16 cycles each) and, in a
-// second kernel, a chain of dependent v_fma_f64; wall time from s_memrealtime (100 MHz).  build: hipcc --offload-arch=gfx950 -O2
+// What is the shader clock under a latency-bound launch, and what does a dependent fp64 instruction cost?  One wavefront per CU
+// runs a loop of s_nop 15 and, in a second kernel, a chain of dependent v_fma_f64 (measured: 2.62 ns = 6.3 cycles per link -- the
+// floor of every single-wavefront recursion in the engines: 5.8 cycles per instruction in the factorisation sweep); wall time from s_memrealtime (100 MHz).  build: hipcc --offload-arch=gfx950 -O2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void nops(long long *out, int iters)
@@ -35,8 +36,9 @@ int main()
             nops<<<blocks, 64>>>(d, it);
             hipDeviceSynchronize();
             hipMemcpy(h, d, blocks * 8, hipMemcpyDeviceToHost);
-            const double sec = h[0] * 1e-8, cyc = (double)it * 8 * 16;
-            printf("s_nop loop, %3d wavefronts: %.3f s for %.3g nop cycles (+ loop overhead) -> >= %.2f GHz\n", blocks, sec, cyc, cyc / sec * 1e-9);
+            // (s_nop 15 holds the wavefront for 16 QUAD cycles + its own issue: 68 cycles -- 28.5 ns here = 2.39 GHz, the clock
+            // GRBM_GUI_ACTIVE / 8 XCDs / kernel time gives for the real kernels as well)
+            printf("s_nop 15, %3d wavefronts: %.2f ns each\n", blocks, h[0] * 10.0 / ((double)it * 8));
             const int itf = 1000000;
             fmas<<<blocks, 64>>>(d, sink, itf, 0.999999, 1e-9);
             hipDeviceSynchronize();
