@@ -48,22 +48,30 @@ def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk,
     np.testing.assert_array_equal(out["qp_iter"][0], ref["qp_iter"])
 
 
-def test_emulated_engine_active_bounds_and_batch(orc, ur10, ur10_rb):
-    """Tight input bounds (active from the first step) and non-default per-instance parameters."""
+@pytest.mark.parametrize("N,T,pool,waves", [(15, 0.3, 0, 4), (15, 0.3, 9156, 4), (120, 0.06, 9156, 4), (120, 0.06, 0, 8), (130, 0.05, 0, 4)])
+def test_emulated_engine_active_bounds_and_batch(orc, ur10, ur10_rb, N, T, pool, waves):
+    """Tight input bounds (active from the first step) and non-default per-instance parameters -- through the streaming sweeps
+    (short horizon), the register-resident sweeps (half a pool; N = 120: two segments), the LDS-resident factor (N = 120, whole
+    pool) and the LDS segments (N = 130)."""
     import emu
 
     cfgs = [
-        _cfg(prediction_horizon=15, simulation_time=0.3, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
+        _cfg(prediction_horizon=N, simulation_time=T, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
              qdot_0=np.array([0.5, 0.7, 0.5, 0, 0, 0.0])),
-        _cfg(prediction_horizon=15, simulation_time=0.3, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
+        _cfg(prediction_horizon=N, simulation_time=T, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
              w_qddot=0.05, px_ref=0.5, vy_ref=-0.02, surface_coeffs=dict(a=-0.1, b=0.12, c=0.0, d=0.02, e=-0.01, f=0.05)),
     ]
-    out = emu.run(cfgs, ur10, waves=4)
+    out = emu.run(cfgs, ur10, pool_doubles=pool, waves=waves)
+    # At N = 120 the first QP of the tight-bound simulation stops at qp_solver_iter_max (50 iterations, status 0 under SQP_RTI): an
+    # interior-point iterate that has NOT converged is reproduced to 1e-9 .. 1e-10 only -- by every sweep implementation alike
+    # (streaming sweeps 1.2e-9 / 3e-10 depending on the chunking, register sweeps 1.1e-9, resident factor 5e-11): 1e-8 there.
+    atol = 1e-9 if N < 100 else 1e-8
     for i, cfg in enumerate(cfgs):
         ref = orc.run(ur10_rb, orc.make_params(cfg))
-        np.testing.assert_allclose(out["z"][i], ref["z"], atol=1e-9, rtol=0)
-        np.testing.assert_allclose(out["u"][i], ref["u"], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(out["z"][i], ref["z"], atol=atol, rtol=0)
+        np.testing.assert_allclose(out["u"][i], ref["u"], atol=atol, rtol=0)
         np.testing.assert_array_equal(out["status"][i], ref["status"])
+        np.testing.assert_array_equal(out["qp_iter"][i], ref["qp_iter"])
     assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6  # the bound is really hit
 
 

@@ -109,6 +109,33 @@ def test_active_bounds_and_heterogeneous_parameters(eng, orc, ur10, ur10_rb):
     assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6
 
 
+@pytest.mark.parametrize("N,T", [(100, 0.3), (130, 0.2)])
+def test_active_bounds_with_two_simulations_per_cu(orc, ur10, ur10_rb, monkeypatch, N, T):
+    """The geometry of every batch beyond 256 simulations (two per CU, half the LDS pool each: chunk-parallel sweeps with the factor
+    in registers, one and two segments) with input bounds that are active from the first step, a tilted surface with its own
+    weights, and absent position bounds -- against the oracle."""
+    from robotic_mpc_amd import engine
+
+    cfgs = [
+        _cfg(prediction_horizon=N, simulation_time=T, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
+             qdot_0=np.array([0.5, 0.7, 0.5, 0, 0, 0.0])),
+        _cfg(prediction_horizon=N, simulation_time=T, wcv=np.array([150., 180., 200., 120., 90., 60.]), w_u=0.001,
+             w_qddot=0.05, px_ref=0.5, vy_ref=-0.02, surface_coeffs=dict(a=-0.1, b=0.12, c=0.0, d=0.02, e=-0.01, f=0.05)),
+        _cfg(prediction_horizon=N, simulation_time=T, q_min=np.full(6, -1e30), q_max=np.full(6, 1e30)),
+    ]
+    monkeypatch.setenv("MPCB_SIMS_PER_CU", "2")
+    e = engine.MpcBatchEngine(0)
+    out = e.run(cfgs, ur10)
+    geo = e.launch_info()
+    e.close()
+    assert geo["engine"] == 0 and geo["waves_per_sim"] == 4 and geo["pool_bytes"] < 80000, geo
+    # (the first QP of the tight-bound simulation stops at qp_solver_iter_max: an unconverged interior-point iterate is reproduced
+    # to ~1e-9 only, by every sweep implementation alike -- tests/test_emulation.py has the figures; iteration counts stay equal)
+    for i, c in enumerate(cfgs):
+        _check(out, i, orc.run(ur10_rb, orc.make_params(c)), atol=1e-8 if i == 0 else ATOL)
+    assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6
+
+
 def test_plant_integrators_per_simulation(eng, orc, ur10, ur10_rb):
     """Euler / RK2 / RK3 / RK4 plant (simulation_model.py:39-49,93-117) mixed inside ONE batch."""
     cfgs = [_cfg(prediction_horizon=12, simulation_time=0.3, integration_method=m) for m in ("Euler", "RK2", "RK3", "RK4")]
