@@ -2452,10 +2452,22 @@ struct Engine {
     }
 
     // =========================================================================== SQP line search
-    // One pass of the L1 merit function (acados ocp_nlp_evaluate_merit_fun restated) at the trial
-    // point (X,U) + alpha (dX,dU).  With `update_weights` the merit weights are first refreshed
+    // The L1 merit function (acados ocp_nlp_evaluate_merit_fun restated) at the trial points (X,U) + alpha_g (dX,dU), g < na, in ONE
+    // pass: the stages of a trial point are one lane each, so a horizon of up to 127 stages keeps only two wavefronts busy -- the
+    // other wavefronts of the simulation evaluate the NEXT step length of the backtracking sequence at the same time (two trial
+    // points per pass); the records are staged through LDS once for both.  Each value is the
+    // same sum, in the same order, as a pass of its own would form.  With `update_weights` the merit weights are first refreshed
     // from the QP multipliers by Leineweber's rule (acados merit_backtracking_*_weights).
-    MPC_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
+    static constexpr int MERIT_MAX = 2;     // (four at eight wavefronts measured slower: the speculative trial points share the SIMDs of the two that count)
+    MPC_HD int merit_lanes() const                       // lanes per trial point: whole wavefronts, as many as stages if possible
+    {
+        const int NS = ex.uni(ex.smem().n_hor) + 1;
+        int lpg = NT < 2 * WAVE ? NT : 2 * WAVE;
+        while (lpg < NS && lpg < NT) lpg *= 2;
+        return lpg;
+    }
+    MPC_HD int merit_groups() const { return imin(MERIT_MAX, imax(1, NT / merit_lanes())); }
+    MPC_PASS void merit_pass(const double *alphas, int na, bool update_weights, int sqp_iter, double *out)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
@@ -2463,14 +2475,17 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(ex.smem().n_hor);
         constexpr int WMW = 36, LMW = 38;   // 36 merit weights per stage; LDS row stride 38 (lane <-> stage accesses: no bank aliasing)
-        constexpr int LVT = 22;   // per-stage scratch in LDS: trial state (12) | task residual record (8); a local array would live in scratch memory
-        const int CH = chunk_len(L1 + LMW + LVT, L1);
-        double total = 0.0;
+        constexpr int LVT = 22;   // per-stage and trial-point scratch in LDS: trial state (12) | task residual record (8); a local array would live in scratch memory
+        const int LPG = merit_lanes();                   // lanes per trial point (trial point g: lanes [g LPG, (g + 1) LPG))
+        const int CH = chunk_len(L1 + LMW + LVT * na, L1);
+        double al[MERIT_MAX];
+#pragma unroll
+        for (int g = 0; g < MERIT_MAX; g++) { al[g] = g < na ? alphas[g] : 0.0; out[g] = 0.0; }
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl), hi = imin(k1 + 1, Nl);
             double *v1 = ex.pool();                        // rows k0..hi, L1
             double *vm = v1 + (size_t)(CH + 1) * L1;    // rows k0..k1, MW
-            double *vt = vm + (size_t)CH * LMW;         // rows k0..k1, trial point and its task residual
+            double *vt = vm + (size_t)CH * LMW;         // [trial point][rows k0..k1]: trial state and its task residual
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W1, 0, W1, L1, true, NL>(v1, ex.smem().w.G1, k0, hi, lane);
@@ -2489,12 +2504,17 @@ struct Engine {
                 });
                 copy_rect<WMW, O_MW, W5, LMW, false>(vm, ex.smem().w.G5, k0, k1);
             }
-            ex.par([&](int lane) {
+            ex.par([&](int lane_) {
+                const int g = lane_ / LPG, lane = lane_ - g * LPG;
+                double alpha = al[0];
+#pragma unroll
+                for (int j = 1; j < MERIT_MAX; j++) alpha = g == j ? al[j] : alpha;
                 double acc = 0.0;
-                for (int k = k0 + lane; k <= k1; k += NT) {
+                if (g < na) {
+                for (int k = k0 + lane; k <= k1; k += LPG) {
                     const double *r1 = v1 + (size_t)(k - k0) * L1, *rn = r1 + L1;
                     const double *mw = vm + (size_t)(k - k0) * LMW;
-                    double *xx = vt + (size_t)(k - k0) * LVT, *rec = xx + 12;   // task_lin<false> only writes rec[O_R..O_R+4]
+                    double *xx = vt + ((size_t)g * CH + (k - k0)) * LVT, *rec = xx + 12;   // task_lin<false> only writes rec[O_R..O_R+4]
                     double uu[6];
 #pragma unroll
                     for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i] + alpha * r1[O_QW + 6 + i];
@@ -2526,12 +2546,18 @@ struct Engine {
                         for (int i = 0; i < 12; i++) acc += sm.w.state[13 + i] * fabs(sm.xhat[i] - xx[i]);
                     }
                 }
-                ex.put_sum(sm.red[0], lane, acc);
+                }
+                ex.put_wsum(sm.red[0], lane_, acc);     // one partial per wavefront: a trial point's are consecutive
             });
-            total += ex.get_sum(sm.red[0]);
+            // combine the wavefronts of each trial point (same order in every lane)
+            {
+                const int wpg = LPG / WAVE;
+#pragma unroll
+                for (int g = 0; g < MERIT_MAX; g++)
+                    if (g < na) out[g] += ex.get_sum_range(sm.red[0], g * wpg, wpg);
+            }
         }
         PROF_ADD(PF_MERIT, t0);
-        return total;
     }
 
     // Merit weight of the eliminated x_0 constraint: |stage-0 stationarity of the QP wrt x_0|
@@ -2566,11 +2592,22 @@ struct Engine {
     MPC_HD double line_search(int sqp_iter)
     {
         update_x0_weights(sqp_iter);
-        const double m0 = merit_pass(0.0, true, sqp_iter);
-        double alpha = 1.0;
+        const int G = merit_groups();
+        // the backtracking sequence is fixed (1, 0.7, 0.49, ...): G trial points per pass, the reference point 0 in the first
+        double al[MERIT_MAX], m[MERIT_MAX], m0 = 0.0, alpha = 1.0;
+        bool first = true;
         while (alpha >= 0.05) {
-            if (ex.uni(merit_pass(alpha, false, sqp_iter) < m0)) break;
-            alpha *= 0.7;
+            int na = 0;
+            if (first) al[na++] = 0.0;
+            double a = alpha;
+            while (na < G && a >= 0.05) { al[na++] = a; a *= 0.7; }
+            merit_pass(al, na, first, sqp_iter, m);
+            int j = 0;
+            if (first) { m0 = m[0]; j = 1; first = false; }
+            for (; j < na; j++) {
+                if (ex.uni(m[j] < m0)) return al[j];
+                alpha = al[j] * 0.7;
+            }
         }
         return alpha;
     }

@@ -247,6 +247,14 @@ struct DevExec {
     __device__ __forceinline__ static void put1_min(double *r, int lane, double v) { const double t = wave_reduce(v, OpMin()); if (lane == 0) r[0] = t; }
     __device__ __forceinline__ static double get1(const double *r) { return uni(r[0]); }
     __device__ __forceinline__ static double get_sum(const double *r) { return get(r, OpSum()); }
+    // per-wavefront partial sums (put_sum leaves exactly those) and the sum over wavefronts [w0, w0 + n)
+    __device__ __forceinline__ static void put_wsum(double *r, int lane, double v) { put(r, lane, v, OpSum()); }
+    __device__ __forceinline__ static double get_sum_range(const double *r, int w0, int n)
+    {
+        double tot = r[w0];
+        for (int w = 1; w < n; w++) tot += r[w0 + w];
+        return uni(tot);
+    }
     __device__ __forceinline__ static double get_max(const double *r) { return get(r, OpMax()); }
     __device__ __forceinline__ static double get_min(const double *r) { return get(r, OpMin()); }
     // constant 100 MHz counter (s_memrealtime)

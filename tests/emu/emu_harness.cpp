@@ -94,6 +94,13 @@ struct HostExec {
     static void put1_min(double *r, int lane, double v) { put_min(r, lane, v); }
     static double get1(const double *r) { return r[0]; }
     static double get_sum(const double *r) { return r[0]; }
+    static void put_wsum(double *r, int lane, double v) { r[lane >> 6] = (lane & 63) == 0 ? v : r[lane >> 6] + v; }
+    static double get_sum_range(const double *r, int w0, int n)
+    {
+        double tot = r[w0];
+        for (int w = 1; w < n; w++) tot += r[w0 + w];
+        return tot;
+    }
     static double get_max(const double *r) { return r[0]; }
     static double get_min(const double *r) { return r[0]; }
     double clock() { return 0.0; }
