@@ -630,7 +630,11 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         {
             const int NS = p->N + 1, scr = h->pool_doubles - (NS * 102 + 16 * 144);
             // (measured: N = 100 665 k vs 651 k; N = 50 1.045 M vs 1.054 M; N = 20 1.59 M vs 1.68 M -- short horizons have too few items)
-            if (wpc == 1 && p->N >= 80 && scr >= 4096 && scr >= NS * 30 + 2 * 16 * 12 + 16) nw = 8;
+            const bool resident = scr >= 4096 && scr >= NS * 30 + 2 * 16 * 12 + 16;
+            // longer horizons at one simulation per CU run the same sweeps one LDS segment at a time (Engine::segment_ok): eight
+            // wavefronts there as well (batch 256, N = 200: 244.8 k vs 234.5 k steps/s; N = 300: 144.5 k vs 137.9 k)
+            const bool segments = !resident && h->pool_doubles >= SEG_POOL_FULL;
+            if (wpc == 1 && p->N >= 80 && (resident || segments)) nw = 8;
         }
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }
         if (const char *e3 = getenv("MPCB_WPE")) { if (atoi(e3) == 2 && nw == 4) wpe = 2; else if (atoi(e3) == 1) wpe = 1; }
