@@ -187,3 +187,22 @@ def reference_errors_loop(ee_pose, ee_vel, coeffs, t_ee, px_ref, vy_ref):
         e["p_task_z"][i] = z
     e["p_ee_y"] = p_ee_all[1, :]
     return e
+
+
+def random_parameter_cfgs(n, seed, **kw):
+    """Seeded random draws over every per-simulation parameter of the parameter record: weights, references, surface, bandwidths,
+    start state, integrator, and bounds from wide to tight (some active from the first step)."""
+    from robotic_mpc_amd import config
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        tight = rng.uniform(0.6, 3.2)
+        out.append(config.resolve_config(config.base_params(
+            q_0=config.BASE_PARAMS["q_0"] + rng.uniform(-0.15, 0.15, 6), qdot_0=rng.uniform(-0.5, 0.5, 6),
+            wcv=rng.uniform(60.0, 250.0, 6), w_u=float(10 ** rng.uniform(-3, -1.5)), w_qddot=float(10 ** rng.uniform(-2.3, -1)),
+            px_ref=float(rng.uniform(0.3, 0.55)), vy_ref=float(rng.uniform(-0.05, 0.08)),
+            surface_coeffs={k: float(v) for k, v in zip("abcdef", rng.normal([-0.1, 0.1, -0.01, 0.01, 0.01, 0.0], 0.03))},
+            qdot_min=np.full(6, -tight), qdot_max=np.full(6, tight),
+            integration_method=["RK4", "RK4", "Euler", "RK2", "RK3"][int(rng.integers(5))], **kw)))
+    return out

@@ -75,6 +75,28 @@ def test_emulated_engine_active_bounds_and_batch(orc, ur10, ur10_rb, N, T, pool,
     assert np.abs(out["u"][0][:, 1:]).max() > 0.8 - 1e-6  # the bound is really hit
 
 
+@pytest.mark.parametrize("N,T,solver,pool,waves", [(30, 0.2, "SQP_RTI", 0, 4), (30, 0.1, "SQP", 2048, 2), (100, 0.08, "SQP_RTI", 0, 8),
+                                                    (100, 0.08, "SQP_RTI", 9156, 4), (140, 0.05, "SQP_RTI", 0, 8)])
+def test_emulated_random_parameter_records(orc, ur10, ur10_rb, N, T, solver, pool, waves):
+    """Every field of the parameter record drawn at random (the draws of tests/test_gpu_parity.py
+    test_random_parameter_records_match_oracle, six simulations each) through the host emulation of the device code: streaming,
+    LDS-resident, register-resident and segment sweeps against the oracle, strict up to the first flagged step."""
+    import emu
+    import helpers as hp
+
+    so = {"nlp_solver_type": solver, "qp_solver_iter_max": 50 if N < 100 else 120}
+    cfgs = hp.random_parameter_cfgs(12, seed=1000 + N + len(solver), prediction_horizon=N, simulation_time=T, solver_options=so)[:6]
+    out = emu.run(cfgs, ur10, pool_doubles=pool, waves=waves)
+    for i, c in enumerate(cfgs):
+        ref = orc.run(ur10_rb, orc.make_params(c))
+        bad = np.nonzero((ref["status"] != 0) | (out["status"][i] != 0))[0]
+        n = int(bad[0]) if bad.size else ref["status"].shape[0]
+        for k in ("status", "sqp_iter", "qp_iter"):
+            np.testing.assert_array_equal(out[k][i][:n], ref[k][:n], err_msg=f"sim {i} {k}")
+        for k in ("z", "u", "ee_pose"):
+            np.testing.assert_allclose(out[k][i][:, :n + 1], ref[k][:, :n + 1], atol=1e-9, rtol=0, err_msg=f"sim {i} {k}")
+
+
 @pytest.mark.parametrize("method", ["Euler", "RK2", "RK3"])
 def test_emulated_plant_integrators(orc, ur10, ur10_rb, method):
     """simulation_model.py:39-49: the plant integrator is a per-simulation parameter."""
