@@ -51,7 +51,8 @@ def _check(out, i, ref, atol=ATOL):
 
 
 @pytest.mark.parametrize("N,T,B", [(20, 1.0, 4), (100, 0.3, 2), (1, 0.1, 1), (2, 0.1, 2), (3, 0.05, 1), (7, 0.2, 3), (130, 0.05, 2),
-                                   (300, 0.03, 1)])
+                                   (300, 0.03, 1),
+                                   (245, 0.03, 1), (246, 0.03, 1)])   # the longest horizon whose y fits the ring (item-parallel residual pass) and the first beyond (sequential pass)
 def test_stream_engine_matches_oracle(stream_engine, orc, ur10, ur10_rb, N, T, B):
     cfgs = _jitter(B, seed=N, prediction_horizon=N, simulation_time=T)
     out = stream_engine.run(cfgs, ur10)
