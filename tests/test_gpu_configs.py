@@ -71,7 +71,7 @@ def test_config2_grid_search_buckets_match_oracle(config2_run, orc, ur10_rb):
     # Closed-loop sensitivity: for the long-horizon corners of this grid (N=200, w_qddot=0.02, w_u=0.01) a
     # perturbation of the state grows by ~1.18x per MPC step over the last ~100 steps, so two fp64 implementations
     # that agree to 1e-14 per step drift apart to 1e-4 by step 600 with IDENTICAL status / iteration counts at every
-    # step (scripts/gpu_dbg_n200.py).  Strict parity (1e-9) is therefore asserted over the first
+    # step (tests/tools/gpu_dbg_n200.py).  Strict parity (1e-9) is therefore asserted over the first
     # STRICT steps of every spot check and over the whole run wherever the drift stays below it; iteration counts and
     # statuses must agree at every step of every spot check.
     STRICT = 400

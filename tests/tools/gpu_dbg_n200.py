@@ -1,5 +1,7 @@
+"""Test tooling (it uses the oracle, so it lives under tests/): the long-horizon grid corner of configs[2] on the GPU against the oracle,
+step by step -- where the two drift apart and that the solver decisions stay equal."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import orc
