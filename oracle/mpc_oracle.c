@@ -648,6 +648,82 @@ static double ipm_alpha(int N, const double *lam, const double *t, const ipm_ws 
     return alpha;
 }
 
+/* which bound sides exist: inputs on stages 0..N-1, joint positions wherever lb/ub is finite (the caller
+ * passes +-1e30 on the stages without position bounds, trajectory_optimizer.py:164-171) */
+static int ipm_build_mask(int N, const double *lb, const double *ub, unsigned char *mask)
+{
+    int nc = 0;
+    for (int k = 0; k <= N; k++)
+        for (int j = 0; j < NB; j++) {
+            int has_u = (j < NU) ? (k < N) : 1;
+            mask[(size_t)k * 24 + j] = has_u && lb[(size_t)k * NB + j] > -BIG;
+            mask[(size_t)k * 24 + 12 + j] = has_u && ub[(size_t)k * NB + j] < BIG;
+            nc += mask[(size_t)k * 24 + j] + mask[(size_t)k * 24 + 12 + j];
+        }
+    return nc;
+}
+
+/* BOUND-INACTIVE FAST PATH (not HPIPM: an addition of this build, orc_params.fast_path).  The QP is strictly convex
+ * (SURVEY A.6), so when its EQUALITY-constrained minimiser -- one Riccati factorisation with Gamma = 0, started from
+ * w = 0 with x_0 embedded -- keeps every bounded component at least ORC_FAST_MARGIN inside its bounds, that point is
+ * the QP's solution with all bound multipliers 0, and the interior-point loop (which would need two factorisations
+ * to bring lam*t from the 0.1 warm-start clamp down to qp_tol) is skipped.  Returns 1 and writes (w, pi, lam = 0,
+ * t = slack) on acceptance; returns 0 and leaves the warm start (w, pi, lam, t) UNTOUCHED otherwise.
+ * Replaces nothing in the reference's results beyond qp_tol: simulator.py:212 sees the same u to ~1e-9. */
+#define ORC_FAST_MARGIN 1e-3
+static int ipm_fast_path(int N, const double *H, const double *g, const double *b, const double *A, const double *B,
+                         const double *lb, const double *ub, const double *dx0, double *w, double *pi, double *lam,
+                         double *t, ipm_ws *ws)
+{
+    ipm_build_mask(N, lb, ub, ws->mask);
+    for (int k = 0; k <= N; k++) {
+        double *Ht = ws->Ht + (size_t)k * 324, *gt = ws->gt + (size_t)k * NW;
+        memcpy(Ht, H + (size_t)k * 324, 324 * sizeof(double));
+        for (int i = 0; i < NW; i++) {
+            double s = g[(size_t)k * NW + i];
+            if (k == 0) for (int j = 0; j < NX; j++) s += Ht[i * NW + NU + j] * dx0[j];   /* H_0 [0; dx0] */
+            gt[i] = s;
+        }
+        if (k == 0) for (int j = 0; j < NX; j++) gt[NU + j] = 0;   /* x_0 is eliminated */
+        if (k == N) for (int j = 0; j < NU; j++) gt[j] = 0;        /* no input at stage N */
+        if (k < N) {
+            double *rbk = ws->rb + (size_t)k * NX;
+            for (int i = 0; i < NX; i++) {
+                double s = b[(size_t)k * NX + i];
+                if (k == 0) for (int j = 0; j < NX; j++) s += A[i * NX + j] * dx0[j];
+                rbk[i] = s;
+            }
+        }
+    }
+    if (ipm_riccati(N, A, B, ws, 1)) return 0;
+    /* candidate = [0; dx0] + dw ; accept when every bounded component clears its bounds by the margin; a NaN anywhere
+     * rejects (nothing has been written yet: the warm start stays as it was) */
+    for (int k = 0; k <= N; k++) {
+        const unsigned char *mk = ws->mask + (size_t)k * 24;
+        for (int i = 0; i < NW; i++) {
+            double v = ws->dw[(size_t)k * NW + i] + ((k == 0 && i >= NU) ? dx0[i - NU] : 0.0);
+            if (v != v) return 0;
+            if (i < NB) {
+                if (mk[i] && !(v - lb[(size_t)k * NB + i] >= ORC_FAST_MARGIN)) return 0;
+                if (mk[12 + i] && !(ub[(size_t)k * NB + i] - v >= ORC_FAST_MARGIN)) return 0;
+            }
+        }
+    }
+    for (int k = 0; k <= N; k++) {
+        const unsigned char *mk = ws->mask + (size_t)k * 24;
+        for (int i = 0; i < NW; i++)
+            w[(size_t)k * NW + i] = ws->dw[(size_t)k * NW + i] + ((k == 0 && i >= NU) ? dx0[i - NU] : 0.0);
+        if (k < N) memcpy(pi + (size_t)k * NX, ws->dpi + (size_t)k * NX, NX * sizeof(double));
+        for (int j = 0; j < NB; j++) {
+            double v = w[(size_t)k * NW + j];
+            lam[(size_t)k * 24 + j] = 0; lam[(size_t)k * 24 + 12 + j] = 0;
+            t[(size_t)k * 24 + j] = mk[j] ? v - lb[(size_t)k * NB + j] : 1.0;
+            t[(size_t)k * 24 + 12 + j] = mk[12 + j] ? ub[(size_t)k * NB + j] - v : 1.0;
+        }
+    }
+    return 1;
+}
+
 /* Mehrotra predictor-corrector IPM; restates HPIPM's d_ocp_qp_ipm_solve main loop
  * (init with warm_start=2: keep everything, clamp lam,t >= 0.1; predictor; sigma =
  * (mu_aff/mu)^3; centering-corrector on the same factorisation; step
@@ -658,18 +734,11 @@ static int ipm_solve(int N, const double *H, const double *g, const double *b, c
 {
     const double thr0 = 0.1, alpha_min = 1e-12, lam_min = 1e-16, t_min = 1e-16;
     size_t nlt = ((size_t)N + 1) * 24;
-    int nc = 0;
-    for (int k = 0; k <= N; k++)
-        for (int j = 0; j < NB; j++) {
-            int has_u = (j < NU) ? (k < N) : 1;
-            ws->mask[(size_t)k * 24 + j] = has_u && lb[(size_t)k * NB + j] > -BIG;
-            ws->mask[(size_t)k * 24 + 12 + j] = has_u && ub[(size_t)k * NB + j] < BIG;
-        }
+    const int nc = ipm_build_mask(N, lb, ub, ws->mask);
     for (size_t i = 0; i < nlt; i++) {
         if (ws->mask[i]) {
             if (lam[i] < thr0) lam[i] = thr0;
             if (t[i] < thr0) t[i] = thr0;
-            nc++;
         } else { lam[i] = 0; t[i] = 1; }
     }
     for (int i = 0; i < NX; i++) w[NU + i] = dx0[i];
@@ -736,6 +805,20 @@ int orc_qp_ipm(int N, const double *H, const double *g, const double *b, const d
     return st;
 }
 
+/* the fast path on a raw QP (tests): 1 = accepted, (w, pi, lam, t) hold the solution; 0 = rejected, they are untouched */
+int orc_qp_fast(int N, const double *H, const double *g, const double *b, const double *A, const double *B,
+                const double *lb, const double *ub, const double *dx0, double *w, double *pi, double *lam, double *t)
+{
+    ipm_ws ws;
+    double *mem = (double *)calloc(ipm_ws_doubles(N), sizeof(double));
+    unsigned char *mask = (unsigned char *)calloc(((size_t)N + 1) * 24, 1);
+    if (!mem || !mask) { free(mem); free(mask); return -1; }
+    ipm_ws_carve(&ws, N, mem, mask);
+    int ok = ipm_fast_path(N, H, g, b, A, B, lb, ub, dx0, w, pi, lam, t, &ws);
+    free(mem); free(mask);
+    return ok;
+}
+
 /* ------------------------------------------------------------------ */
 /* NLP layer: acados SQP / SQP_RTI restated                            */
 /* ------------------------------------------------------------------ */
@@ -758,6 +841,8 @@ struct orc_solver {
     ipm_ws ws;
     double *wsmem;
     unsigned char *mask;
+    int fast_skip, fast_back; /* fast path: QPs left before the next attempt; length of the current suspension */
+    int n_fast, n_reject;  /* diagnostics: accepted / rejected attempts */
 };
 
 orc_solver *orc_solver_create(const orc_robot *rb, const orc_params *p)
@@ -939,12 +1024,31 @@ static void nlp_residuals(const orc_solver *s, const double *xhat, double *res4)
     res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc;
 }
 
+/* One QP.  `iters` counts Riccati FACTORISATIONS: one per interior-point iteration, plus one for a fast-path attempt.
+ * The fast path is attempted at every QP, except that a REJECTED attempt (some bound within the margin: the factorisation
+ * was wasted) suspends the attempts for the next 1, 2, 4, 8, 8, ... QPs of this solver (doubling while the rejections go on,
+ * back to none after an acceptance), so that a simulation riding its bounds pays at most one wasted factorisation in nine. */
 static int solve_qp(orc_solver *s, const double *xhat, int *iters)
 {
     double dx0[12];
+    int tried = 0, it = 0;
     for (int i = 0; i < 12; i++) dx0[i] = xhat[i] - s->x[i];
-    return ipm_solve(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt,
-                     s->p.qp_tol, s->p.qp_iter_max, iters, NULL, &s->ws);
+    if (s->p.fast_path && s->fast_skip > 0 && s->p.fast_path != 2) s->fast_skip--;
+    else if (s->p.fast_path) {
+        tried = 1;
+        if (ipm_fast_path(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt, &s->ws)) {
+            s->fast_back = 0; s->n_fast++;
+            *iters = 1;
+            return 0;
+        }
+        s->fast_back = s->fast_back ? (2 * s->fast_back < 8 ? 2 * s->fast_back : 8) : 1;
+        s->fast_skip = s->fast_back;
+        s->n_reject++;
+    }
+    int st = ipm_solve(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt,
+                       s->p.qp_tol, s->p.qp_iter_max, &it, NULL, &s->ws);
+    *iters = it + tried;
+    return st;
 }
 
 /* acados ocp_nlp_update_variables_sqp restated */
@@ -1136,6 +1240,7 @@ int orc_run(const orc_robot *rb, const orc_params *p, orc_output *o)
         memcpy(z, zn, sizeof z);
         log_state(rb, o, T1, i + 1, z, u);
     }
+    if (getenv("ORC_FAST_STATS")) fprintf(stderr, "fast path: accepted %d rejected %d of %d steps\n", s->n_fast, s->n_reject, p->Nsim);
     orc_solver_destroy(s);
     return 0;
 }

@@ -59,6 +59,10 @@ typedef struct {
     double tol_eq, tol_ineq, tol_comp;
     /* acados levenberg_marquardt (default 0): dt*lm*I is added to every stage Hessian, lm*I to the terminal one */
     double lm;
+    /* bound-inactive fast path of the QP solve (an addition of this build, see ipm_fast_path in mpc_oracle.c):
+     * 0 off (every QP through the interior-point loop, as HPIPM), 1 on (attempted by the rule in solve_qp),
+     * 2 attempted at every QP (diagnostic) */
+    int fast_path;
 } orc_params;
 
 /* Per-instance outputs, C-contiguous [row][time] like the reference's logs
@@ -106,6 +110,13 @@ int orc_qp_ipm(int N, const double *H, const double *g, const double *b, const d
                const double *B, const double *lb, const double *ub, const double *dx0,
                double *w, double *pi, double *lam, double *t, double tol, int iter_max,
                int *iters, double *res4);
+
+/* The bound-inactive fast path on the same data (an addition of this build, not HPIPM; see ipm_fast_path): one Riccati
+ * solve of the equality-constrained QP from w = 0; returns 1 and writes (w, pi, lam = 0, t = slack) when every bounded
+ * component clears its bounds by 1e-3, else returns 0 and leaves (w, pi, lam, t) untouched. */
+int orc_qp_fast(int N, const double *H, const double *g, const double *b, const double *A,
+                const double *B, const double *lb, const double *ub, const double *dx0,
+                double *w, double *pi, double *lam, double *t);
 
 /* ---- whole closed loop (simulator.py:199-241) ---- */
 int orc_run(const orc_robot *rb, const orc_params *p, orc_output *out);

@@ -33,6 +33,7 @@ class Params(C.Structure):
         ("w_u", C.c_double), ("w_qddot", C.c_double), ("px_ref", C.c_double), ("vy_ref", C.c_double),
         ("coeffs", C.c_double * 6), ("w_task", C.c_double * 5), ("integrator", C.c_int),
         ("tol_eq", C.c_double), ("tol_ineq", C.c_double), ("tol_comp", C.c_double), ("lm", C.c_double),
+        ("fast_path", C.c_int),
     ]
 
 
@@ -89,6 +90,7 @@ def make_params(cfg: Dict) -> Params:
     p.integrator = int(cfg.get("plant_integrator", 0))
     p.tol_eq = float(cfg.get("tol_eq", 0.0)); p.tol_ineq = float(cfg.get("tol_ineq", 0.0)); p.tol_comp = float(cfg.get("tol_comp", 0.0))
     p.lm = float(cfg.get("levenberg_marquardt", 0.0))
+    p.fast_path = int(cfg.get("qp_fast_path", 1))
     return p
 
 
@@ -168,6 +170,23 @@ def qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-8, iter_max=50, warm=None):
                           _ptr(w), _ptr(pi), _ptr(lam), _ptr(t), C.c_double(tol), C.c_int(iter_max),
                           C.byref(iters), _ptr(res))
     return dict(w=w, pi=pi, lam=lam, t=t, status=st, iters=iters.value, res=res)
+
+
+def qp_fast(H, g, b, A, B, lb, ub, dx0, warm=None):
+    """The bound-inactive fast path on one OCP-QP; returns dict(accepted, w, pi, lam, t) -- the warm start unchanged when rejected."""
+    N = H.shape[0] - 1
+    H = np.ascontiguousarray(H, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64); A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64); lb = np.ascontiguousarray(lb, dtype=np.float64)
+    ub = np.ascontiguousarray(ub, dtype=np.float64); dx0 = np.ascontiguousarray(dx0, dtype=np.float64)
+    if warm is None:
+        w = np.zeros((N + 1, 18)); pi = np.zeros((max(N, 1), 12)); lam = np.zeros((N + 1, 24)); t = np.zeros((N + 1, 24))
+    else:
+        w, pi, lam, t = (np.ascontiguousarray(v, dtype=np.float64).copy() for v in warm)
+    lib().orc_qp_fast.restype = C.c_int
+    ok = lib().orc_qp_fast(C.c_int(N), _ptr(H), _ptr(g), _ptr(b), _ptr(A), _ptr(B), _ptr(lb), _ptr(ub), _ptr(dx0),
+                           _ptr(w), _ptr(pi), _ptr(lam), _ptr(t))
+    return dict(accepted=int(ok), w=w, pi=pi, lam=lam, t=t)
 
 
 def run(rb: Robot, p: Params) -> Dict[str, np.ndarray]:

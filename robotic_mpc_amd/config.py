@@ -31,7 +31,12 @@ EXTENSION_DEFAULTS = {"translation_ee_t": (0.0, 0.0, 0.1), "urdf_path": None, "e
                       "integration_method": "RK4",
                       # arithmetic of the Riccati factor / solve sweeps: "fp64" (the reference's) or "fp32"
                       # (BASELINE configs[4]; SQP_RTI only)
-                      "riccati_precision": "fp64"}
+                      "riccati_precision": "fp64",
+                      # bound-inactive fast path of the QP solve (csrc/mpc_ipm.h): a QP whose equality-constrained minimiser is strictly
+                      # inside every bound is solved by ONE Riccati factorisation instead of the interior-point loop (same solution to
+                      # well below qp_tol).  False: every QP goes through the HPIPM-style loop, as in the reference's solver.solve()
+                      # (simulator.py:212)
+                      "qp_fast_path": True}
 # codes of the parameter record (include/mpcbatch.h [7]); RK4 = 0 keeps default records unchanged
 PLANT_INTEGRATORS = {"RK4": 0, "Euler": 1, "RK2": 2, "RK3": 3}
 
@@ -253,6 +258,7 @@ def resolve_config(config: Mapping[str, Any]) -> Dict[str, Any]:
         "tol_comp": so["nlp_solver_tol_comp"], "qp_tol": so["qp_tol"], "levenberg_marquardt": so["levenberg_marquardt"],
         "fixed_step": so["globalization"] == "FIXED_STEP",
         "precision": 1 if cfg["riccati_precision"] == "fp32" else 0,
+        "qp_fast_path": 1 if cfg["qp_fast_path"] else 0,
         "wcv": wcv, "q0": _vec6(cfg, "q_0"), "qdot0": _vec6(cfg, "qdot_0"),
         "qmin": _vec6(cfg, "q_min"), "qmax": _vec6(cfg, "q_max"),
         "umin": _vec6(cfg, "qdot_min"), "umax": _vec6(cfg, "qdot_max"),

@@ -137,11 +137,12 @@ struct Engine {
     Ctx c;
     int N;
     double lin_cost;  // cost of the linearisation currently held in G2
+    int fast_skip, fast_back;   // fast path: QPs left before the next attempt; length of the current suspension (ipm::fast_backoff)
 #ifdef MPCB_PROFILE
     double prof[NPROF];
 #endif
 
-    MPC_HD Engine(Ex &e, const Ctx &cc) : ex(e), c(cc), N(cc.N), lin_cost(0.0)
+    MPC_HD Engine(Ex &e, const Ctx &cc) : ex(e), c(cc), N(cc.N), lin_cost(0.0), fast_skip(0), fast_back(0)
     {
         ex.par([&](int lane) {
             if (lane == 0) { Smem &sm = ex.smem(); sm.w = cc.w; sm.n_hor = cc.N; sm.pool_n = cc.pool_n; }
@@ -1527,10 +1528,12 @@ struct Engine {
     // three sums S_i with mu(alpha) * nc = S0 + alpha S1 + alpha^2 S2.  Only the state recursion
     // dx_{k+1} = A dx_k - B (Kfb dx_k + Rinv h_u) + rb_k is sequential (one phase per stage);
     // Rinv h_u and e = rb - B Rinv h_u come with the factor (written by whoever produced h_u).
-    template <bool AFFINE>
+    // FAST: see fwd_resident (the follower forms the candidate's slacks instead of dlam / dt; returns 1.0 / 0.0).
+    template <bool AFFINE, bool FAST = false>
     // (the centering sums S0, S1, S2 stay in sm.red[1..3][0]: read them with ex.get1)
     MPC_PASS double forward_step_pass()
     {
+        static_assert(!FAST || !AFFINE, "the fast path takes the full step");
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
@@ -1572,8 +1575,11 @@ struct Engine {
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<LF, 0, W4, LF, true, NL>(q4, ex.smem().w.G4, 0, e1, lane);
+                if (FAST) copy_lanes<18, 0, W1, WLT, true, NL>(qlt, ex.smem().w.G1, 0, e1, lane);   // X | U of the NLP iterate
+                else {
                 copy_lanes<48, O_QLAM, W1, WLT, true, NL>(qlt, ex.smem().w.G1, 0, e1, lane);
                 copy_lanes<48, O_RD, W3, WR, true, NL>(qr, ex.smem().w.G3, 0, e1, lane);
+                }
             });
         }
         for (int ci = 0; ci < NCH; ci++) {
@@ -1659,11 +1665,18 @@ struct Engine {
                             // all loads first, decisions on registers only (see corrector_bwd_pass)
                             const bool hc = has_comp(Nl, k, j);
                             const bool blo = hc && bnd_lo(P, j) > -BOUND_INF, bhi = hc && bnd_hi(P, j) < BOUND_INF;
+                            double dtl, dll = 0.0, dtu, dlu = 0.0;
+                            if (FAST) {
+                                const double val = lt[j < 6 ? O_U + j : O_X + j - 6];   // the NLP iterate's u_j / q_{j-6}
+                                const double dvel = dxk[j < 6 ? 6 + j : j];              // (the velocity step of the same joint: NaN check)
+                                const bool good = ipm::fast_side(blo, bhi, dv, bnd_lo(P, j) - val, bnd_hi(P, j) - val, dtl, dtu);
+                                al = good && dv == dv && dvel == dvel ? al : 0.0;
+                            } else {
                             const double ll = lt[j], tl = lt[24 + j], lu = lt[12 + j], tu = lt[36 + j];
                             const double rdl = r[j], rdu = r[12 + j], rml = r[24 + j], rmu = r[36 + j];
-                            double dtl, dll, dtu, dlu;
                             ipm::lam_t_side(blo, dv, ll, tl, rdl, rml, al, a0, a1, a2, dtl, dll);
                             ipm::lam_t_side(bhi, -dv, lu, tu, rdu, rmu, al, a0, a1, a2, dtu, dlu);
+                            }
                             o[30 + j] = dll; o[42 + j] = dlu;   // DLAM lower | upper
                             o[54 + j] = dtl; o[66 + j] = dtu;   // DT lower | upper
                         }
@@ -1680,8 +1693,11 @@ struct Engine {
                 constexpr int NL = decltype(nl)::value;
                 if (nk0 <= Nl) {
                     copy_lanes<LF, 0, W4, LF, true, NL>(n4, ex.smem().w.G4, nk0, nk1, lane);
+                    if (FAST) copy_lanes<18, 0, W1, WLT, true, NL>(nlt, ex.smem().w.G1, nk0, nk1, lane);
+                    else {
                     copy_lanes<48, O_QLAM, W1, WLT, true, NL>(nlt, ex.smem().w.G1, nk0, nk1, lane);
                     copy_lanes<48, O_RD, W3, WR, true, NL>(nr, ex.smem().w.G3, nk0, nk1, lane);
+                    }
                 }
                 if (k0 > 0) {
                     if (AFFINE) copy_lanes<48, O_DLAM, W3, WO, false, NL>(po + 30, ex.smem().w.G3, k0 - CH, k0 - 1, lane);
@@ -2035,10 +2051,14 @@ struct Engine {
     // KREG (with SEG): nothing of the factor in LDS -- the recursion holds its share of K in registers (rs_recursion_reg), the items
     // load their row of K and R~^-1 h_u from the HBM record themselves, after the recursion (one batch of one item per lane at a
     // time: the register budget of two simulations per CU is 256).
-    template <bool AFFINE, bool SEG, bool KREG = false>
+    // FAST (bound-inactive fast path, mpc_ipm.h): the Newton system is the equality-constrained QP's at w = 0, so the step IS the
+    // candidate solution; instead of dlam / dt / step length the items form the candidate's slacks (-> G3 DT) and the pass returns
+    // 1.0 when every bounded component clears its bounds by ipm::FAST_MARGIN (and nothing is NaN), else 0.0.
+    template <bool AFFINE, bool SEG, bool KREG = false, bool FAST = false>
     MPC_PASS double fwd_resident()
     {
         static_assert(!KREG || SEG, "register mode runs segment by segment");
+        static_assert(!FAST || !AFFINE, "the fast path takes the full step");
         PROF_T0(t0);
         Smem &sm = ex.smem();
         const InstParams &P = sm.P;
@@ -2065,6 +2085,9 @@ struct Engine {
                     for (int r = 0; r < R; r++) {
                         const int e = imin(base + r * NT + lane, items - 1), kl = e / 6, j = e - kl * 6, k = kb + kl;
                         const double *g1 = G1 + (size_t)k * W1, *g3 = G3 + (size_t)k * W3;
+                        if (FAST) {
+                            ld[r][0].at(lane) = gld(g1 + O_U + j); ld[r][8].at(lane) = gld(g1 + O_X + j);   // the NLP iterate's u_j, q_j
+                        } else {
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             const int c = j + 6 * h;
@@ -2072,6 +2095,7 @@ struct Engine {
                             ld[r][8 * h + 2].at(lane) = gld(g1 + O_QT + c);   ld[r][8 * h + 3].at(lane) = gld(g1 + O_QT + 12 + c);
                             ld[r][8 * h + 4].at(lane) = gld(g3 + O_RD + c);   ld[r][8 * h + 5].at(lane) = gld(g3 + O_RD + 12 + c);
                             ld[r][8 * h + 6].at(lane) = gld(g3 + O_RM + c);   ld[r][8 * h + 7].at(lane) = gld(g3 + O_RM + 12 + c);
+                        }
                         }
                         if (KREG) {
                             const double *g4 = G4 + (size_t)(kb + imin(kl, nt - 1)) * W4;
@@ -2142,9 +2166,15 @@ struct Engine {
                                 const bool blo = ok && sm.bon[c] != 0.0, bhi = ok && sm.bon[12 + c] != 0.0;
                                 const double dv = h == 0 ? du : dq;
                                 double dtl, dll, dtu, dlu;
+                                if (FAST) {
+                                    const double val = ld[r][8 * h].at(lane);
+                                    const bool good = ipm::fast_side(blo, bhi, dv, bnd_lo(P, c) - val, bnd_hi(P, c) - val, dtl, dtu);
+                                    al = good && dv == dv && dxk[6 + j] == dxk[6 + j] ? al : 0.0;
+                                } else {
                                 side(blo, dv, ld[r][8 * h + 0].at(lane), ld[r][8 * h + 2].at(lane), ld[r][8 * h + 4].at(lane), ld[r][8 * h + 6].at(lane), dtl, dll);
                                 side(bhi, -dv, ld[r][8 * h + 1].at(lane), ld[r][8 * h + 3].at(lane), ld[r][8 * h + 5].at(lane), ld[r][8 * h + 7].at(lane), dtu, dlu);
                                 gst(g3 + O_DLAM + c, dll); gst(g3 + O_DLAM + 12 + c, dlu);
+                                }
                                 gst(g3 + O_DT + c, dtl);   gst(g3 + O_DT + 12 + c, dtu);
                             }
                         }
@@ -2381,6 +2411,140 @@ struct Engine {
         PROF_ADD(PF_BWD, t0);
     }
 
+    // =========================================================================== bound-inactive fast path (mpc_ipm.h)
+    // Right-hand side of the equality-constrained QP's Newton system at w = 0 with x_0 embedded (dx0 = x_hat - x_0): no bound terms,
+    //   Gamma = 0 ; gt = g (stage 0: + H_0 [0; dx0], x rows eliminated) ; rb = b (stage 0: + A dx0)
+    // from the linearisation the NLP pass left in G2 (r -> y = W r, G, the dynamics defect).  Joint items (k, j < 6), operands straight
+    // from HBM like the S phase of residual_direct, whose formulas these are at (dw, pi, lam) = 0.
+    MPC_PASS void fast_rhs()
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2;
+        constexpr int R = rounds_for(6);
+        const int items = NS * 6;
+        const double dt = P.dt;
+        for (int base = 0; base < items; base += R * NT) {
+            ex.wpar([&](int lane) {
+                double v[R][16];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = imin(base + r * NT + lane, items - 1), k = e / 6, j = e - k * 6;
+                    const double *g1 = G1 + (size_t)k * W1, *g2 = G2 + (size_t)k * W2;
+                    v[r][0] = gld(g1 + O_U + j); v[r][1] = gld(g1 + O_X + 6 + j); v[r][2] = gld(g1 + O_X + j);
+                    v[r][3] = gld(g2 + O_GV + j);
+#pragma unroll
+                    for (int i = 0; i < NTASK; i++) { v[r][4 + i] = gld(g2 + O_GQ + i * 6 + j); v[r][9 + i] = gld(g2 + O_Y + i); }
+                    v[r][14] = gld(g2 + O_BD + j); v[r][15] = gld(g2 + O_BD + 6 + j);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int e = base + r * NT + lane;
+                    if (e < items) {
+                        const int k = e / 6, j = e - k * 6;
+                        const bool st = k < Nl;
+                        const double dxq = k == 0 ? sm.xhat[j] - v[r][2] : 0.0, dxv = k == 0 ? sm.xhat[6 + j] - v[r][1] : 0.0;
+                        const double uj = v[r][0], vj = v[r][1] + dxv;
+                        const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NTASK; i++) s_ += v[r][4 + i] * v[r][9 + i];
+                        const double gtu = st ? dt * (2.0 * P.w_u * uj + c2 * (uj - vj)) : 0.0;
+                        const double gtq = st && k >= 1 ? dt * s_ : 0.0;
+                        const double gtv = st && k >= 1 ? dt * (v[r][3] * v[r][13] + c2 * (vj - uj)) : 0.0;
+                        const double rbq = st ? (dxq + P.a12[j] * dxv) + v[r][14] : 0.0;
+                        const double rbv = st ? P.a22[j] * dxv + v[r][15] : 0.0;
+                        double *g2 = G2 + (size_t)k * W2;
+                        gst(g2 + O_GT + j, gtu); gst(g2 + O_GT + 6 + j, gtq); gst(g2 + O_GT + 12 + j, gtv);
+                        gst(g2 + O_GAM + j, 0.0); gst(g2 + O_GAM + 6 + j, 0.0);
+                        gst(g2 + O_RB + j, rbq); gst(g2 + O_RB + 6 + j, rbv);
+                    }
+                }
+            });
+        }
+        ex.barrier();
+        PROF_ADD(PF_RES, t0);
+    }
+
+    // The accepted candidate becomes the QP iterate: (QW | QPI) <- (DW | DPI), x_0 embedded; QLAM <- 0; QT <- the slacks the forward
+    // sweep left in DT (1 on absent sides).  Stage 0's y = W (r + G [dx0]) is refreshed for the SQP merit weights (update_x0_weights).
+    MPC_PASS void fast_commit()
+    {
+        PROF_T0(t0);
+        Smem &sm = ex.smem();
+        const InstParams &P = sm.P;
+        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
+        double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3;
+        {
+            constexpr int IPS = 15, R = rounds_for(IPS);
+            const int items = NS * IPS;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    D2 stp[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                        stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)(c >= 18 ? imin(k + 1, Nl) : k) * W3 + O_DW + c);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / IPS, c = 2 * (e - k * IPS);
+                            D2 v = stp[r];
+                            if (c >= 18 && k >= Nl) { v.x = 0.0; v.y = 0.0; }              // no multiplier beyond the last dynamics
+                            if (k == 0 && c >= 6 && c < 18) {                                // x_0 = x_hat (lbx_0 = ubx_0)
+                                v.x = sm.xhat[c - 6] - gld(G1 + O_X + c - 6); v.y = sm.xhat[c - 5] - gld(G1 + O_X + c - 5);
+                            }
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QW + c) = v;
+                        }
+                    }
+                });
+            }
+        }
+        {
+            constexpr int IPS = 24, R = rounds_for(IPS);
+            const int items = NS * IPS;
+            for (int base = 0; base < items; base += R * NT) {
+                ex.wpar([&](int lane) {
+                    D2 stp[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
+                        stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)k * W3 + O_DT + (q >= 24 ? q - 24 : 0));
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int e = base + r * NT + lane;
+                        if (e < items) {
+                            const int k = e / IPS, q = 2 * (e - k * IPS);
+                            D2 v = stp[r];
+                            if (q < 24) { v.x = 0.0; v.y = 0.0; }
+                            *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QLAM + q) = v;
+                        }
+                    }
+                });
+            }
+        }
+        ex.wpar([&](int lane) {
+            if (lane < NTASK) {
+                const int i = lane;
+                double v = gld(G2 + O_R + i);
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += gld(G2 + O_GQ + i * 6 + j) * (sm.xhat[j] - gld(G1 + O_X + j));
+                if (i == 4) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v += gld(G2 + O_GV + j) * (sm.xhat[6 + j] - gld(G1 + O_X + 6 + j));
+                }
+                gst(G2 + O_Y + i, P.w_task[i] * v);
+            }
+        });
+        ex.barrier();
+        PROF_ADD(PF_RES, t0);
+    }
+
     // =========================================================================== IPM driver
     // Restates HPIPM's d_ocp_qp_ipm_solve main loop (see oracle/mpc_oracle.c ipm_solve).
     // Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
@@ -2394,6 +2558,31 @@ struct Engine {
 #ifdef MPC_EMU_TRACE
         { static int once = 0; if (!once) { once = 1; fprintf(stderr, "[emu] res %d reg %d seg %d pool %d\n", (int)res, (int)reg, (int)seg, (int)ex.smem().pool_n); } }
 #endif
+        // bound-inactive fast path first (mpc_ipm.h; oracle solve_qp): `iters_out` counts Riccati factorisations
+        int tried = 0;
+        if (ex.uni(sm.P.fast_off == 0.0)) {
+            if (fast_skip > 0) fast_skip--;
+            else {
+                tried = 1;
+                fast_rhs();
+                double ok;
+                if (res) { fact_pass_t<1>(); ok = fwd_resident<false, false, false, true>(); }
+                else if (reg) { fact_pass_t<2>(); ok = fwd_resident<false, true, true, true>(); }
+                else if (seg) { fact_pass_t<2>(); ok = fwd_resident<false, true, false, true>(); }
+                else { fact_pass_t<0>(); ok = forward_step_pass<false, true>(); }
+                if (ex.uni(ok > 0.5)) {
+                    fast_commit();
+                    fast_back = 0;
+#ifdef MPCB_PROFILE
+                    prof[PF_COUNT_IPM] += 1;
+#endif
+                    *iters_out = 1;
+                    return 0;
+                }
+                fast_back = ipm::fast_backoff(fast_back);
+                fast_skip = fast_back;
+            }
+        }
         residual_direct(0, 0.0);
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
@@ -2445,9 +2634,9 @@ struct Engine {
             mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
         }
 #ifdef MPCB_PROFILE
-        prof[PF_COUNT_IPM] += it;
+        prof[PF_COUNT_IPM] += it + tried;
 #endif
-        *iters_out = it;
+        *iters_out = it + tried;
         return status;
     }
 
@@ -2696,6 +2885,7 @@ struct Engine {
             });
             lin_cost = w.state[12];
             lin_valid = ex.uni(w.state[25] != 0.0);
+            fast_skip = ex.uni((int)w.state[26]); fast_back = ex.uni((int)w.state[27]);
         }
         for (int i = step0; i < step1; i++) {
             int sqp_iter = 0, qp_iter = 0;
@@ -2738,7 +2928,7 @@ struct Engine {
         if (log_lo <= step1) log_flush(out, inst, log_lo, step1);   // the columns of a partly filled block
         ex.par([&](int lane) {
             if (lane < NX) w.state[lane] = sm.xhat[lane];
-            if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; }
+            if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; w.state[26] = fast_skip; w.state[27] = fast_back; }
 #ifdef MPCB_PROFILE
             if (lane < NPROF) {
                 double v = prof[0];

@@ -66,5 +66,22 @@ MPC_HD double corrector_side(bool on, double l, double t, double dl_aff, double 
     return on ? (rmv + l * rd) * fast_rcp(t) : 0.0;
 }
 
+// ---- bound-inactive fast path (both engines; oracle/mpc_oracle.c ipm_fast_path is the restatement) -----------------------------
+// The GN QP is strictly convex, so when its EQUALITY-constrained minimiser (one Riccati factorisation with Gamma = 0, from w = 0
+// with x_0 embedded) keeps every bounded component at least FAST_MARGIN inside its bounds, it IS the QP's solution with all bound
+// multipliers zero, and the interior-point loop -- two factorisations to bring lam t from the 0.1 warm-start clamp below qp_tol --
+// is skipped.  Accepted: (w, pi) = the solve's, lam = 0, t = slack.  Rejected: the warm start is untouched and the loop runs as
+// before.  A rejected attempt suspends further attempts for 1, 2, 4, 8, 8, ... QPs (back to none after an acceptance).
+constexpr double FAST_MARGIN = 1e-3;
+// slack of one bound side of a candidate step dv (lo / hi: the bound relative to the NLP iterate) and the acceptance test;
+// an absent side holds t = 1.  NaN fails the comparison, i.e. rejects.
+MPC_HD bool fast_side(bool on_lo, bool on_hi, double dv, double lo, double hi, double &t_lo, double &t_hi)
+{
+    t_lo = on_lo ? dv - lo : 1.0;
+    t_hi = on_hi ? hi - dv : 1.0;
+    return (!on_lo || t_lo >= FAST_MARGIN) && (!on_hi || t_hi >= FAST_MARGIN);
+}
+MPC_HD int fast_backoff(int back) { return back ? (2 * back < 8 ? 2 * back : 8) : 1; }
+
 }  // namespace ipm
 }  // namespace mpcb

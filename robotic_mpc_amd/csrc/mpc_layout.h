@@ -77,7 +77,8 @@ constexpr int O_NPI = 0, O_NLAM = 12, O_NT = 36, O_TX = 60, O_TU = 72, O_MW = 78
 
 constexpr int STAGE_DOUBLES = W1 + W2 + W3 + W4 + W5;
 // [0..11] plant state z, [12] cost of the held linearisation, [13..24] merit weights of the x0
-// constraint, [25] linearisation-valid flag, [32..47] profile counters (diagnostic build)
+// constraint, [25] linearisation-valid flag, [26] fast path: QPs left before the next attempt, [27] length of the
+// current suspension, [32..47] profile counters (diagnostic build)
 constexpr int STATE_DOUBLES = 64;
 constexpr int NPROF = 16;
 
@@ -101,6 +102,7 @@ struct InstParams {
     // acados nlp_solver_tol_eq / _ineq / _comp (`tol` above is nlp_solver_tol_stat)
     double tol_eq, tol_ineq, tol_comp;
     double n_hor;       // this simulation's prediction horizon when it differs from the launch's (throughput engine: ragged batches); 0 = Problem::N
+    double fast_off;    // 0: the bound-inactive fast path of the QP solve is on (mpc_ipm.h, ipm::FAST_MARGIN); 1: every QP through the interior-point loop
 };
 
 // Batch-uniform problem description (== mpcb_problem).

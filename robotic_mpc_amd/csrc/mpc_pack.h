@@ -4,7 +4,8 @@
 //   [8..13] wcv  [14..19] q_0  [20..25] qdot_0  [26..31] q_min  [32..37] q_max
 //   [38..43] qdot_min  [44..49] qdot_max  [50..55] surface coeffs a..f  [56..60] task weights
 //   [61] nlp_solver_tol_eq [62] nlp_solver_tol_ineq [63] nlp_solver_tol_comp  (0: same as [1] = tol_stat)
-//   [64] levenberg_marquardt   [65] this simulation's prediction horizon (0: the launch's N)   [66..71] reserved
+//   [64] levenberg_marquardt   [65] this simulation's prediction horizon (0: the launch's N)
+//   [66] 1: bound-inactive fast path of the QP solve OFF (0, the default: on)   [67..71] reserved
 #pragma once
 #include <math.h>
 
@@ -17,7 +18,7 @@ namespace mpcb {
 inline void pack_inst_params(const double *p, InstParams *P)
 {
     P->dt = p[0]; P->tol = p[1]; P->qp_tol = p[2]; P->w_u = p[3]; P->w_qddot = p[4];
-    P->px_ref = p[5]; P->vy_ref = p[6]; P->integ = p[7]; P->lm = p[64]; P->n_hor = p[65];
+    P->px_ref = p[5]; P->vy_ref = p[6]; P->integ = p[7]; P->lm = p[64]; P->n_hor = p[65]; P->fast_off = p[66];
     P->tol_eq = p[61] > 0.0 ? p[61] : p[1]; P->tol_ineq = p[62] > 0.0 ? p[62] : p[1]; P->tol_comp = p[63] > 0.0 ? p[63] : p[1];
     for (int j = 0; j < 6; j++) {
         P->wcv[j] = p[8 + j]; P->q0[j] = p[14 + j]; P->qdot0[j] = p[20 + j];

@@ -381,10 +381,15 @@ struct IpmNorms {
 // residual norms of the previous step's iterate are formed here -- from the rows as they arrive, i.e. before the
 // warm-start clamp touches lam, t -- and the separate sweep disappears.  nlp_out = [cost, stat, eq, ineq, comp];
 // sm.vec[3] holds the x_hat the previous QP was solved for.  The output bundle then carries G2 [R..BD] (210 doubles).
+// MODE 3 / 4 = right-hand side of the bound-inactive FAST PATH (mpc_ipm.h; mpc_core.h fast_rhs), plain / fused like MODE 2: the same
+// sweep evaluated at (dw, pi, lam) = 0 with x_0 embedded and no bound terms -- Gamma = 0, gt = g, rb = b (+ A dx0 at stage 0) -- and
+// WITHOUT the warm-start clamp: the previous QP's (w, pi, lam, t) in G1 stay as they are (only the x_0 embedding, which MODE 0 would
+// write identically, and y go out), so a rejected attempt is followed by residual_pass<0> as if nothing had happened.
 template <int MODE>
 SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
 {
-    constexpr bool FUSE = MODE == 2;
+    constexpr bool FUSE = MODE == 2 || MODE == 4;
+    constexpr bool FASTM = MODE >= 3;
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
     const int lane = threadIdx.x;
@@ -493,9 +498,9 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             if (lane < NW) row[O_QW + lane] += a * row[I_D + lane];
         } else {
             if (kr == 0 && lane < NX) row[O_QW + 6 + lane] = xh - row[O_X + lane];
-            if (kr == N && lane >= 12 && lane < 18) row[O_QW + lane - 12] = 0.0;
+            if (!FASTM && kr == N && lane >= 12 && lane < 18) row[O_QW + lane - 12] = 0.0;
         }
-        if (lane >= 18 && lane < 30) {
+        if (!FASTM && lane >= 18 && lane < 30) {
             const int j = lj;
             const bool hc = j < 6 ? kr < N : (kr >= 1 && kr < N);
             const bool blo = hc && lj_lo, bhi = hc && lj_hi;
@@ -593,7 +598,10 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             pin(gv0); pin(gv1); pin(gv2); pin(gv3); pin(gv4); pin(gv5);
             double l0 = nxt[O_QLAM + lj], t0 = nxt[O_QT + lj], l1 = nxt[O_QLAM + 12 + lj], t1 = nxt[O_QT + 12 + lj];
             pin(l0); pin(t0); pin(l1); pin(t1);
-            if (k + 1 <= N) {
+            if (FASTM && k > 0) {   // dw = 0 beyond the embedded x_0
+                wq0 = wq1 = wq2 = wq3 = wq4 = wq5 = 0.0; wv0 = wv1 = wv2 = wv3 = wv4 = wv5 = 0.0;
+            }
+            if (!FASTM && k + 1 <= N) {
                 // (upd_row of the lookahead row on registers: warm-start clamp; the row is never row 0)
                 const int kr = k + 1;
                 if (kr == N && lane >= 12 && lane < 18) nxt[O_QW + lane - 12] = 0.0;
@@ -632,6 +640,18 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             pin(l_lo); pin(t_lo); pin(l_hi); pin(t_hi);
             pin(g0); pin(g1); pin(g2); pin(g3); pin(g4); pin(gv); pin(y0); pin(y1); pin(y2); pin(y3); pin(y4);
             pin(q_h); pin(q_n); pin(c1); pin(c2);
+            if (FASTM) {
+                // (dw, pi, lam) = 0: only the embedded x_0 part of stage 0 survives
+                if (lane < NW) {
+                    q_b = 0.0; q_e = 0.0; q_f = 0.0; q_h = 0.0;
+                    q_d = k == 0 ? q_d : 0.0; q_g = 0.0;
+                } else if (lane < 30) {
+                    // dynamics rows: q_a = dx_k[lj], q_b = dv_lj (lj < 6) | du_(lj-6), q_c = du_lj, q_n = dx_{k+1}[lj]
+                    q_a = k == 0 ? q_a : 0.0;
+                    q_b = k == 0 && lj < 6 ? q_b : 0.0;
+                    q_c = 0.0; q_n = 0.0;
+                }
+            }
             if (lane < NW) {
                 // stationarity of the QP at w + dw (mpc_core.h stat_cls with `with_delta`), same operation order
                 double rg = 0.0;
@@ -666,7 +686,7 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
                 double gt = rg;
                 if (cls < 2) {
                     const bool hc = cls == 0 ? k < N : (k >= 1 && k < N);
-                    const bool blo = hc && c_lo, bhi = hc && c_hi;
+                    const bool blo = !FASTM && hc && c_lo, bhi = !FASTM && hc && c_hi;
                     const double v = hc ? q_v : 0.0, dv = q_g;
                     // both sides are evaluated in every lane and masked by selects (an absent bound holds lam = 0, t = 1:
                     // its terms are exact zeros or are deselected), in the operation order of the branchy form
@@ -1230,9 +1250,13 @@ SE_PASS void fact_pass()
 struct StepInfo {
     double alpha, S0, S1, S2;
 };
-template <class FT, bool AFFINE>
+// FAST (bound-inactive fast path, mpc_ipm.h): the step is the candidate solution of the equality-constrained QP; the lagging role
+// forms the candidate's slacks (-> DT; DLAM = 0) from the NLP iterate's u, q instead of dlam / dt, and `alpha` comes back 1.0 when
+// every bounded component clears its bounds by ipm::FAST_MARGIN (and nothing is NaN), else 0.0.
+template <class FT, bool AFFINE, bool FAST = false>
 SE_PASS StepInfo forward_pass()
 {
+    static_assert(!FAST || !AFFINE, "the fast path takes the full step");
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
     const int lane = threadIdx.x;
@@ -1246,7 +1270,8 @@ SE_PASS StepInfo forward_pass()
     Bundle<NII, ITEMS> bin;
     Bundle<1, AFFINE ? 24 : 39> bout;
     {
-        const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)};
+        // (FAST: the first 48 columns of the G1 row -- X | U of the NLP iterate -- ride in the slot of [QLAM, QT]: same bundle shape)
+        const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, FAST ? 0 : O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)};
         bin.setup(si, lane);
         if (AFFINE) { const Seg so[1] = {segd(w.G3, w.ld, O_DLAM, 48)}; bout.setup(so, lane); }
         else { const Seg so[1] = {segd(w.G3, w.ld, O_DW, 78)}; bout.setup(so, lane); }
@@ -1266,6 +1291,8 @@ SE_PASS StepInfo forward_pass()
     const int lo12 = lane < 12 ? lane : 0, lov = lane < 6 ? lane + 6 : (lane < 12 ? lane : 0);
     const int jl = lane >= 48 && lane < 60 ? lane - 48 : 0;        // lagging role: bounded component
     const bool jl_lo = bnd_lo(P, jl) > -BOUND_INF, jl_hi = bnd_hi(P, jl) < BOUND_INF;
+    const double jb_lo = bnd_lo(P, jl), jb_hi = bnd_hi(P, jl);
+    const int jl_val = jl < 6 ? O_U + jl : O_X + jl - 6;           // FAST: the bounded variable itself in the G1 row
     if (lane < NX) sm.vec[0][lane] = 0.0;                          // dx_0 = 0: x_0 is pinned by the init pass
     auto stage = [&](int k, double *row_, double *, double *rowp_) {
         const double *row = row_, *rowp = rowp_;                   // rowp: row k-1, the previous row of this forward sweep
@@ -1283,8 +1310,9 @@ SE_PASS StepInfo forward_pass()
         FT e1 = fac[ex];
         double own_d = dxk[lo12], ov_d = dxk[lov];
         const double *lt = rowp + I_LT, *r = rowp + I_R;
-        double dvl = op[jl], ll = lt[jl], tl = lt[24 + jl], lu = lt[12 + jl], tu = lt[36 + jl];
+        double dvl = op[jl], ll = lt[FAST ? jl_val : jl], tl = lt[24 + jl], lu = lt[12 + jl], tu = lt[36 + jl];
         double rdl = r[jl], rdu = r[12 + jl], rml = r[24 + jl], rmu = r[36 + jl];
+        if (FAST) rdl = op[12 + (jl < 6 ? jl : jl - 6)];           // (the velocity step of the same joint: NaN check)
 #pragma unroll
         for (int j = 0; j < NX; j++) { asm volatile("" : "+v"(m[j])); pin(x[j]); }
         asm volatile("" : "+v"(e1));
@@ -1310,6 +1338,11 @@ SE_PASS StepInfo forward_pass()
             const bool hc = j < 6 ? kp < N : (kp >= 1 && kp < N);
             const bool blo = hc && jl_lo, bhi = hc && jl_hi;
             double dtl = 0, dll = 0, dtu = 0, dlu = 0;
+            if (FAST) {
+                const double val = ll;                              // the NLP iterate's u_j / q_(j-6) of stage k-1
+                const bool good = ipm::fast_side(blo, bhi, dv, jb_lo - val, jb_hi - val, dtl, dtu);
+                al = good && dv == dv && rdl == rdl ? al : 0.0;
+            } else {
             if (blo) {
                 dtl = dv + rdl;
                 dll = -(rml + ll * dtl) * fast_rcp(tl);
@@ -1323,6 +1356,7 @@ SE_PASS StepInfo forward_pass()
                 if (dlu < 0 && lu + al * dlu < 0) al = -lu * fast_rcp(dlu);
                 if (dtu < 0 && tu + al * dtu < 0) al = -tu * fast_rcp(dtu);
                 a0 += lu * tu; a1 += lu * dtu + tu * dlu; a2 += dlu * dtu;
+            }
             }
             op[30 + j] = dll; op[42 + j] = dlu;
             op[54 + j] = dtl; op[66 + j] = dtu;
@@ -1489,6 +1523,71 @@ SE_PASS void corrector_pass(double sigma_mu)
     });
 }
 
+// =============================================================================================== fast path: commit
+// The accepted candidate becomes the QP iterate (mpc_core.h fast_commit): (QW | QPI) <- (DW | DPI), QLAM <- 0, QT <- the slacks in DT.
+// Item-parallel, straight from / to the stage records.  The x part of stage 0 keeps the embedded x_hat - x_0 the right-hand-side
+// pass wrote (the sweep's dx_0 is 0); stage 0's y already holds W (r + G [dx0]).
+SE_PASS void fast_commit()
+{
+    SSmem &sm = g_ssm;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor), NS = N + 1;
+    const SWs w = sm.w;
+    const int LD = uni(w.ld >> 3);
+    MPC_GLOBAL char *const gb = (MPC_GLOBAL char *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)w.G1 >> 32)) << 32) |
+                                                    (unsigned)uni((int)(unsigned long long)w.G1));
+    auto rec = [&](int k, int col) { return (MPC_GLOBAL double *)(gb + (unsigned)((k * LD + col) << 3)); };
+    constexpr int C3 = W1 + W2;
+    wait_vm<0>();
+    fence();
+    {
+        constexpr int IPS = 15, R = 8;
+        const int items = NS * IPS;
+        for (int base = 0; base < items; base += R * WAVE) {
+            D2 stp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                stp[r] = *(MPC_GLOBAL const D2 *)(rec(c >= 18 ? imin(k + 1, N) : k, c) + C3 + O_DW);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / IPS, c = 2 * (e - k * IPS);
+                    D2 v = stp[r];
+                    if (c >= 18 && k >= N) { v.x = 0.0; v.y = 0.0; }             // no multiplier beyond the last dynamics
+                    if (!(k == 0 && c >= 6 && c < 18)) *(MPC_GLOBAL D2 *)(rec(k, c) + O_QW) = v;
+                }
+            }
+        }
+    }
+    {
+        constexpr int IPS = 24, R = 8;
+        const int items = NS * IPS;
+        for (int base = 0; base < items; base += R * WAVE) {
+            D2 stp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
+                stp[r] = *(MPC_GLOBAL const D2 *)(rec(k, q >= 24 ? q - 24 : 0) + C3 + O_DT);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = base + r * WAVE + lane;
+                if (e < items) {
+                    const int k = e / IPS, q = 2 * (e - k * IPS);
+                    D2 v = stp[r];
+                    if (q < 24) { v.x = 0.0; v.y = 0.0; }
+                    *(MPC_GLOBAL D2 *)(rec(k, q) + O_QLAM) = v;
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+    fence();
+}
+
 // =============================================================================================== IPM driver
 // HPIPM d_ocp_qp_ipm_solve main loop (mpc_core.h ipm_solve).  Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
 #ifdef MPCB_SPROF
@@ -1498,11 +1597,32 @@ SE_PASS void corrector_pass(double sigma_mu)
 #define SPROF_T0(v)
 #define SPROF_ADD(i, v)
 #endif
+// `fast`: [0] QPs left before the next fast-path attempt, [1] length of the current suspension (ipm::fast_backoff); the fast path
+// runs in fp64 only -- ONE fp32 Riccati solve is not a solution to qp_tol (the fp32 leg refines through the fp64 residuals of the loop).
 template <class FT>
-SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr)
+SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_prev = nullptr)
 {
     SSmem &sm = g_ssm;
     const double tol = sm.P.qp_tol;
+    int tried = 0;
+    if (sizeof(FT) == 8 && uni(sm.P.fast_off == 0.0 ? 1 : 0)) {
+        if (fast[0] > 0) fast[0]--;
+        else {
+            tried = 1;
+            if (nlp_prev) residual_pass<4>(0.0, nlp_prev); else residual_pass<3>(0.0);
+            nlp_prev = nullptr;                                    // the previous step's residuals are done, whatever happens next
+            fact_pass<FT>();
+            const double ok = unid(forward_pass<FT, false, true>().alpha);
+            if (uni(ok > 0.5 ? 1 : 0)) {
+                fast_commit();
+                fast[1] = 0;
+                *iters_out = 1;
+                return 0;
+            }
+            fast[1] = ipm::fast_backoff(fast[1]);
+            fast[0] = fast[1];
+        }
+    }
     // nlp_prev: the NLP residual / cost of the previous step's iterate is still to be evaluated -- by this QP's first pass
     IpmNorms r = nlp_prev ? residual_pass<2>(0.0, nlp_prev) : residual_pass<0>(0.0);
     const double nc = unid(r.nc);
@@ -1554,7 +1674,7 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, double *nlp_prev = nullptr
 #ifdef MPCB_SPROF
     if (threadIdx.x == 0) g_ssm.w.state[32 + 7] += it;
 #endif
-    *iters_out = it;
+    *iters_out = it + tried;
     return status;
 }
 
@@ -1904,6 +2024,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     bool lin_valid = false;
     bool res_pending = false;          // SQP_RTI: cost / residual norms of the previous step are formed by this step's first pass
     double lin_cost = 0.0;
+    int fast[2] = {0, 0};              // fast path: QPs left before the next attempt, length of the current suspension
     int log_lo = step0 == 0 ? 0 : step0 + 1;
     if (step0 == 0) {
         // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0
@@ -1924,6 +2045,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         if (lane < NX) sm.xhat[lane] = w.state[lane];
         lin_cost = unid(w.state[12]);
         lin_valid = uni(w.state[25] != 0.0 ? 1 : 0) != 0;
+        fast[0] = uni((int)w.state[26]); fast[1] = uni((int)w.state[27]);
         fence();
     }
     for (int i = step0; i < step1; i++) {
@@ -1935,7 +2057,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
             // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
             if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass<false>(nullptr)); }
             double nlp_prev[5];
-            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, res_pending ? nlp_prev : nullptr);
+            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, fast, res_pending ? nlp_prev : nullptr);
             if (res_pending) {
                 // cost and residual norms of step i-1, evaluated by this step's first pass
                 if (lane == 8) out.cost[sbase + i - 1] = nlp_prev[0];
@@ -1985,7 +2107,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
                 if (res4[0] < tol && res4[1] < tol_eq && res4[2] < tol_in && res4[3] < tol_co) { status = 0; break; }
                 if (res4[0] != res4[0] || cost != cost) { status = 1; break; }
                 int it = 0;
-                const int qs = ipm_solve<FT>(pb.qp_iter_max, &it);
+                const int qs = ipm_solve<FT>(pb.qp_iter_max, &it, fast);
                 qp_iter += it;
                 if (qs != 0 && qs != 1) { status = 4; break; }
                 __builtin_amdgcn_s_waitcnt(0);
@@ -2057,7 +2179,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     }
     if (log_lo <= step1) log_flush(out, inst, T1, log_lo, step1);
     if (lane < NX) w.state[lane] = sm.xhat[lane];
-    if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; }
+    if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; w.state[26] = fast[0]; w.state[27] = fast[1]; }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 

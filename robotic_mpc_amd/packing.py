@@ -20,6 +20,7 @@ def pack_params(cfg: Dict) -> np.ndarray:
     p[61] = cfg.get("tol_eq", 0.0); p[62] = cfg.get("tol_ineq", 0.0); p[63] = cfg.get("tol_comp", 0.0)
     p[64] = cfg.get("levenberg_marquardt", 0.0)
     p[65] = cfg["N"]    # per-simulation horizon: lets one launch hold simulations of different horizons (ragged bucket)
+    p[66] = 0.0 if cfg.get("qp_fast_path", 1) else 1.0   # 1: fast path of the QP solve OFF
     return p
 
 
@@ -40,6 +41,7 @@ def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
     for col, key in _OPTIONAL:
         p[:, col] = [c.get(key, 0.0) for c in cfgs]
     p[:, 65] = [c["N"] for c in cfgs]
+    p[:, 66] = [0.0 if c.get("qp_fast_path", 1) else 1.0 for c in cfgs]
     return p
 
 

@@ -19,14 +19,21 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+_SURF0 = dict(a=0.0, b=0.0, c=0.0, d=0.0, e=0.0, f=0.0)
 CASES = {
-    # name: (overrides of BASE_PARAMS)
-    "rti_n20": dict(prediction_horizon=20, simulation_time=0.5, solver_options={"nlp_solver_type": "SQP_RTI"}),
-    "sqp_n10": dict(prediction_horizon=10, simulation_time=0.3, solver_options={"nlp_solver_type": "SQP"}),
+    # name: (overrides of BASE_PARAMS).  The first four pin the HPIPM-style interior-point path (every QP through the loop:
+    # qp_fast_path=False, the reference's solver.solve() semantics); the *_fp cases pin the bound-inactive fast path (the default).
+    "rti_n20": dict(prediction_horizon=20, simulation_time=0.5, solver_options={"nlp_solver_type": "SQP_RTI"}, qp_fast_path=False),
+    "sqp_n10": dict(prediction_horizon=10, simulation_time=0.3, solver_options={"nlp_solver_type": "SQP"}, qp_fast_path=False),
     "rti_n100_flat": dict(prediction_horizon=100, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP_RTI"},
-                          surface_coeffs=dict(a=0.0, b=0.0, c=0.0, d=0.0, e=0.0, f=0.0)),
+                          surface_coeffs=_SURF0, qp_fast_path=False),
     "rti_tight_bounds": dict(prediction_horizon=15, simulation_time=0.3, qdot_min=[-0.8] * 6, qdot_max=[0.8] * 6,
-                             qdot_0=[0.5, 0.7, 0.5, 0.0, 0.0, 0.0], solver_options={"nlp_solver_type": "SQP_RTI"}),
+                             qdot_0=[0.5, 0.7, 0.5, 0.0, 0.0, 0.0], solver_options={"nlp_solver_type": "SQP_RTI"}, qp_fast_path=False),
+    "rti_n20_fp": dict(prediction_horizon=20, simulation_time=0.5, solver_options={"nlp_solver_type": "SQP_RTI"}),
+    "sqp_n10_fp": dict(prediction_horizon=10, simulation_time=0.3, solver_options={"nlp_solver_type": "SQP"}),
+    "rti_n100_flat_fp": dict(prediction_horizon=100, simulation_time=0.2, solver_options={"nlp_solver_type": "SQP_RTI"}, surface_coeffs=_SURF0),
+    "rti_tight_bounds_fp": dict(prediction_horizon=15, simulation_time=0.6, qdot_min=[-0.8] * 6, qdot_max=[0.8] * 6,
+                                qdot_0=[0.5, 0.7, 0.5, 0.0, 0.0, 0.0], solver_options={"nlp_solver_type": "SQP_RTI"}),
 }
 KEYS = ("z", "u", "ee_pose", "ee_rpy", "ee_vel", "status", "sqp_iter", "qp_iter", "residuals", "cost")
 
@@ -47,8 +54,14 @@ def main():
     rb = orc.make_robot(chain)
     for name in CASES:
         o = orc.run(rb, orc.make_params(case_config(name)))
-        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **{k: o[k] for k in KEYS})
-        print(name, "steps", o["status"].shape[0], "qp_iter mean", o["qp_iter"].mean())
+        path = os.path.join(HERE, f"{name}.npz")
+        if os.path.exists(path) and "--all" not in sys.argv:
+            # an existing fixture is only rewritten on request: it pins the oracle against regressions
+            g = np.load(path)
+            print(name, "exists; max |oracle - fixture| on z:", float(np.abs(o["z"] - g["z"]).max()))
+            continue
+        np.savez_compressed(path, **{k: o[k] for k in KEYS})
+        print(name, "steps", o["status"].shape[0], "qp_iter mean", o["qp_iter"].mean(), "fast-path steps", int((o["qp_iter"] == 1).sum()))
     # independent kinematic KATs (numpy 4x4 chain, not the oracle)
     rng = np.random.default_rng(123)
     for robot in ("ur10", "ur5"):

@@ -241,6 +241,52 @@ def test_qp_warm_start_reaches_same_solution(orc):
     assert s2["iters"] <= s1["iters"]
 
 
+# ----------------------------------------------------------------------------- QP: bound-inactive fast path
+@pytest.mark.parametrize("N", [1, 7, 40])
+def test_qp_fast_path_is_the_qp_solution_when_no_bound_is_near(orc, N):
+    """Loose bounds: ONE Riccati solve of the equality-constrained QP is accepted, carries an optimality certificate of the
+    inequality-constrained QP computed in numpy from the raw data (lam = 0, t = slack > margin), and is what the interior-point
+    loop converges to."""
+    rng = np.random.default_rng(70 + N)
+    H, g, b, A, B, lb, ub, dx0 = hp.random_ocp_qp(rng, N, scale_g=0.05)
+    lb[:] = np.where(lb > -1e29, lb - 5.0, lb); ub[:] = np.where(ub < 1e29, ub + 5.0, ub)
+    f = orc.qp_fast(H, g, b, A, B, lb, ub, dx0)
+    assert f["accepted"] == 1
+    k = hp.qp_kkt_residuals(H, g, b, A, B, lb, ub, dx0, f["w"], f["pi"], f["lam"], f["t"])
+    assert k["stat"] < 1e-11 and k["prim"] < 1e-12 and k["feas"] == 0.0 and k["comp"] == 0.0 and k["dual"] <= 0
+    has = np.abs(lb) < 1e29
+    has[N, :6] = False
+    np.testing.assert_array_equal(f["t"][:, :12][has], (f["w"][:, :12] - lb)[has])
+    assert f["t"][:, :12][has].min() >= 1e-3 and (f["lam"] == 0).all()
+    # (the loop from a consistent start -- t = the slacks at w = 0; from HPIPM's cold start, t clamped to 0.1 against slacks of ~7,
+    # it stalls on some of these QPs: the same start-up weakness that costs the closed loop its first 6-9 iteration QPs)
+    t0 = np.ones((N + 1, 24)); t0[:, :12] = np.where(has, -lb, 1.0); t0[:, 12:] = np.where(has, ub, 1.0)
+    s = orc.qp_ipm(H, g, b, A, B, lb, ub, dx0, tol=1e-10, iter_max=80, warm=(np.zeros((N + 1, 18)), np.zeros((max(N, 1), 12)), np.zeros((N + 1, 24)), t0))
+    assert s["status"] == 0
+    np.testing.assert_allclose(f["w"], s["w"], atol=1e-8)
+    np.testing.assert_allclose(f["pi"][:N], s["pi"][:N], atol=1e-8)
+
+
+def test_qp_fast_path_rejects_near_active_bounds_and_leaves_the_warm_start_alone(orc):
+    rng = np.random.default_rng(8)
+    H, g, b, A, B, lb, ub, dx0 = hp.random_ocp_qp(rng, 12, tight=True)
+    warm = tuple(rng.normal(size=sh) for sh in ((13, 18), (12, 12), (13, 24), (13, 24)))
+    f = orc.qp_fast(H, g, b, A, B, lb, ub, dx0, warm=warm)
+    assert f["accepted"] == 0
+    for a, b_ in zip((f["w"], f["pi"], f["lam"], f["t"]), warm):
+        np.testing.assert_array_equal(a, b_)
+    # the margin: the unconstrained minimiser itself as upper bound (slack 0) is rejected, 2e-3 away from it is accepted
+    free = orc.qp_fast(H, g, b, A, B, np.full_like(lb, -1e30), np.full_like(ub, 1e30), dx0)
+    assert free["accepted"] == 1
+    ub2 = np.full_like(ub, 1e30); ub2[3, 2] = free["w"][3, 2]
+    assert orc.qp_fast(H, g, b, A, B, np.full_like(lb, -1e30), ub2, dx0)["accepted"] == 0
+    ub2[3, 2] = free["w"][3, 2] + 2e-3
+    assert orc.qp_fast(H, g, b, A, B, np.full_like(lb, -1e30), ub2, dx0)["accepted"] == 1
+    # NaN data never passes
+    gn = g.copy(); gn[5, 3] = np.nan
+    assert orc.qp_fast(H, gn, b, A, B, np.full_like(lb, -1e30), np.full_like(ub, 1e30), dx0)["accepted"] == 0
+
+
 # ----------------------------------------------------------------------------- NLP / closed loop
 def _cfg(**kw):
     from robotic_mpc_amd import config
@@ -380,8 +426,11 @@ def test_oracle_records_solver_failures_and_carries_on(orc, ur10_rb):
     mk = lambda **kw: config.resolve_config(config.base_params(prediction_horizon=10, simulation_time=0.15, **kw))
     r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP", "nlp_solver_max_iter": 2})))
     assert (r["status"] == 2).all() and (r["sqp_iter"] == 2).all() and np.isfinite(r["z"]).all()
-    r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": 3})))
+    r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": 3}, qp_fast_path=False)))
     assert (r["status"] == 0).all() and (r["qp_iter"] == 3).all()
+    # (with the fast path -- the default -- the same QPs are solved outright: one factorisation each, nothing to cap)
+    r = orc.run(ur10_rb, orc.make_params(mk(solver_options={"nlp_solver_type": "SQP_RTI", "qp_solver_iter_max": 3})))
+    assert (r["status"] == 0).all() and (r["qp_iter"][2:] == 1).all()
     bad = mk(q_min=config.BASE_PARAMS["q_0"] + 0.5)          # the initial state violates the position bounds: infeasible QP
     r = orc.run(ur10_rb, orc.make_params(bad))
     assert (r["status"] == 4).all() and np.isfinite(r["z"]).all()
@@ -421,3 +470,39 @@ def test_long_horizon_grid_corner_amplifies_perturbations_in_closed_loop(orc, ur
     assert 1.08 < growth < 1.2, growth                # ~1.12 per MPC step (the GPU-vs-oracle drift showed ~1.18 on another run)
     d100 = pair(100)
     assert d100.max() < 1e-11                         # same weights, N = 100: no amplification
+
+
+# ----------------------------------------------------------------------------- closed loop: fast path of the QP solve
+def test_fast_path_closed_loop_equals_the_interior_point_loop_up_to_the_qp_tolerance(orc, ur10_rb):
+    """qp_fast_path on / off over a whole closed loop.  With the QP tolerance tightened to 1e-12 the two agree to 1e-9 (measured
+    1e-12): the fast path returns the QP's solution.  At the reference's qp_tol = 1e-8 (trajectory_optimizer.py:63) they differ by
+    ~1e-7 -- the interior-point iterate's own distance from the solution, accumulated in the task's null space -- well inside
+    north_star's 1e-6.  Statuses equal; the fast path takes most steps once the start-up transient (active input bounds) is over."""
+    runs = {}
+    for tol in (1e-8, 1e-12):
+        for fast in (True, False):
+            c = _cfg(prediction_horizon=30, simulation_time=2.0, qp_fast_path=fast,
+                     solver_options={"nlp_solver_type": "SQP_RTI", "qp_tol": tol, "qp_solver_iter_max": 200})
+            runs[(tol, fast)] = orc.run(ur10_rb, orc.make_params(c))
+    for tol, bound in ((1e-12, 1e-9), (1e-8, 1e-6)):
+        on, off = runs[(tol, True)], runs[(tol, False)]
+        np.testing.assert_array_equal(on["status"], off["status"])
+        for k in ("z", "u"):
+            np.testing.assert_allclose(on[k], off[k], atol=bound, rtol=0, err_msg=f"qp_tol {tol} {k}")
+    on, off = runs[(1e-8, True)], runs[(1e-8, False)]
+    assert (on["qp_iter"] == 1).mean() > 0.8 and (off["qp_iter"] >= 2).all()      # one factorisation instead of >= 2
+    assert on["qp_iter"].sum() < 0.6 * off["qp_iter"].sum()
+
+
+def test_fast_path_attempts_back_off_while_bounds_stay_active(orc, ur10_rb):
+    """Input bounds active for the whole run: every attempt is rejected, and the attempts thin out to one in nine QPs
+    (suspensions of 1, 2, 4, 8, 8, ... QPs): qp_iter = interior-point iterations + 1 exactly at steps 0, 2, 5, 10, 19, 28, ..."""
+    kw = dict(prediction_horizon=15, simulation_time=0.6, qdot_min=np.full(6, -0.8), qdot_max=np.full(6, 0.8),
+              qdot_0=np.array([0.5, 0.7, 0.5, 0, 0, 0.0]))
+    on = orc.run(ur10_rb, orc.make_params(_cfg(qp_fast_path=True, **kw)))
+    off = orc.run(ur10_rb, orc.make_params(_cfg(qp_fast_path=False, **kw)))
+    assert np.abs(on["u"][:, 1:]).max() > 0.8 - 1e-6
+    np.testing.assert_allclose(on["z"], off["z"], atol=1e-12)        # nothing accepted: the same interior-point path
+    tried = np.nonzero(on["qp_iter"] - off["qp_iter"])[0]
+    assert set(np.unique(on["qp_iter"] - off["qp_iter"])) <= {0, 1}
+    np.testing.assert_array_equal(tried, [0, 2, 5, 10, 19, 28, 37, 46, 55])
