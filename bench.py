@@ -66,7 +66,7 @@ def pmc_traffic(batch, N, Nsim, solver):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
     (profiles/r02_pmc_summary.json, written by scripts/profile_gpu.sh); None when absent or when it was
     taken on another workload.  The summary names the commit it was profiled at."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -98,25 +98,34 @@ def cpu_baseline_main(argv):
     cfgs = workload_configs(batch, N, sim_time, seed=0, solver=solver)
     rb = orc.make_robot(chain)
     Nsim = cfgs[0]["Nsim"]
-    t0 = time.time()
-    done = 0
-    for c in cfgs:     # 1 thread, like the reference's single-threaded acados
-        orc.run(rb, orc.make_params(c))
-        done += 1
-        if time.time() - t0 > budget / 2 or done >= 8:
-            break
-    el = time.time() - t0
-    out = {"value": done * Nsim / el, "unit": "MPC-steps/s", "cores": 1, "kind": "port",
+
+    def timed(fast, limit):
+        t0 = time.time()
+        done = 0
+        for c in cfgs:     # 1 thread, like the reference's single-threaded acados
+            orc.run(rb, orc.make_params({**c, "qp_fast_path": fast}))
+            done += 1
+            if time.time() - t0 > limit or done >= 8:
+                break
+        return done, done * Nsim / (time.time() - t0)
+
+    # `value`: the REFERENCE's algorithm -- every QP through the HPIPM-style interior-point loop (qp_fast_path off), which is what
+    # solver.solve() does (simulator.py:212); `value_fast_path`: the oracle with the same fast path the GPU engine runs by default
+    done, rate = timed(0, budget / 3)
+    done_f, rate_f = timed(1, budget / 6)
+    out = {"value": rate, "unit": "MPC-steps/s", "cores": 1, "kind": "port",
            "sample": f"{done} of the {len(cfgs)} simulations x {Nsim} steps of the bench workload, oracle/mpc_oracle.c "
-                     f"(dense C restatement of the reference algorithm) built here with gcc {' '.join(flags)}, 1 thread",
-           "flags": " ".join(flags)}
+                     f"(dense C restatement of the reference algorithm: every QP through the interior-point loop) built here with gcc "
+                     f"{' '.join(flags)}, 1 thread",
+           "flags": " ".join(flags), "value_fast_path": rate_f,
+           "value_fast_path_note": f"the same oracle with the bound-inactive fast path of the QP solve (the GPU engine's default), {done_f} simulations, 1 thread"}
     import multiprocessing as mp
 
     ncpu = min(os.cpu_count() or 1, 16)
     sample = cfgs[:ncpu]
     t0 = time.time()
     with mp.get_context("fork").Pool(ncpu, initializer=_oracle_init, initargs=(lib,)) as pool:
-        pool.map(_oracle_one, [(chain, c) for c in sample])
+        pool.map(_oracle_one, [(chain, {**c, "qp_fast_path": 0}) for c in sample])
     out.update({"value_all_cores": len(sample) * Nsim / (time.time() - t0), "cores_all": ncpu})
     try:
         os.unlink(lib)
@@ -164,16 +173,12 @@ def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a CHILD process and forward its output and exit code.  This parent has not imported torch or touched HIP (a
     process that has initialised the GPU must never exec or fork GPU work), and it only waits."""
-    import socket
-
-    with socket.socket() as sock:      # a free rendezvous port on the loopback interface
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    # --standalone: the launcher binds its own rendezvous port (no probe-then-reuse race with other processes on the box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__), *sys.argv[1:]]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:           # rank 0's JSON line (and nothing else of ours) arrives here
         sys.stdout.write(line)
@@ -191,7 +196,7 @@ def stream_roofline(kernel_ms: float, B: int, N: int, Nsim: int):
     algo = bytes_per_mpc_step(N) * B * Nsim
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     traffic = src = None
-    for name in ("r03_stream_b4096_pmc.json", "r02_stream_b4096_pmc.json"):
+    for name in ("r04_stream_b4096_pmc.json", "r03_stream_b4096_pmc.json", "r02_stream_b4096_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -237,6 +242,79 @@ def throughput_leg(eng, chain, args):
     return out
 
 
+def config2_surface_sets(n):
+    """SURVEY 8(d) Config 3 / examples/surface_stats.ipynb cells 1+7: every coefficient ~ N(mean, 0.01) around
+    {a:-0.1, b:0.1, c:-0.01, d:0.01, e:0.01, f:0}, np.random.seed(42), keys in dict order a..f per set."""
+    base = dict(a=-0.1, b=0.1, c=-0.01, d=0.01, e=0.01, f=0.0)
+    rs = np.random.RandomState(42)
+    return [{k: float(rs.normal(v, 0.01)) for k, v in base.items()} for _ in range(n)]
+
+
+def config2_main(args, world, rank, multi, cpu_proc):
+    """BASELINE configs[2] as the reference's user would run it: SimulationManager.grid_search over
+    {prediction_horizon: [20, 50, 100, 200], w_qddot: [0.02, 0.05], w_u: [0.01, 0.001]} x coefficient sets, then run_all --
+    sharded over the ranks by distributed.run_partitioned (every rank the same mix of horizons), results gathered to rank 0.
+    One bench step = one run_all of the whole grid (config resolution, packing, launches, gather, D2H): STRONG scaling."""
+    import torch
+    import torch.distributed as dist
+
+    from robotic_mpc_amd import SimulationManager, base_params
+
+    m = SimulationManager(base_params(simulation_time=args.sim_time, solver_options={"nlp_solver_type": args.solver}))
+    m.grid_search({"prediction_horizon": [20, 50, 100, 200], "w_qddot": [0.02, 0.05], "w_u": [0.01, 0.001]},
+                  surface_coeff_sets=config2_surface_sets(args.coeff_sets))
+    n_sims = len(m.simulations)
+    Nsim = int(args.sim_time / 0.01)
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass():
+        return m.run_all(distributed=multi, results=args.results)
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        res = one_pass()
+        kernel_ms.append(m.last_run_info["kernel_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        info = m.last_run_info
+        fails = sum(int(s["num_failures"]) for s in m.last_summaries)
+        line = {
+            "metric": "MPC-steps/sec (whole node), UR10 N=100 dt=0.01 batch; 1/2/4/8 GPU",
+            "value": n_sims * Nsim * args.steps / elapsed, "unit": "MPC-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: grid_search {{N in [20,50,100,200], w_qddot in [0.02,0.05], w_u in [0.01,0.001]}} x "
+                                   f"{args.coeff_sets} surface coefficient sets = {n_sims} simulations x {Nsim} steps, {args.solver}, "
+                                   f"through SimulationManager.run_all(results='{args.results}'), sharded over {world} rank(s)",
+                       "simulations": n_sims, "closed_loop_steps": Nsim, "buckets": info.get("buckets"), "results": args.results,
+                       "timed_region": "run_all: Simulator(**config) x n -> parameter records -> launches of this rank's shard of every "
+                                       "bucket -> summary kernels -> gather to rank 0 -> D2H",
+                       "rank0_kernel_ms_per_pass": float(np.mean(kernel_ms)), "rank0_setup_s": info.get("setup_s"),
+                       "rank0_run_s": info.get("run_s"), "rank0_d2h_s": info.get("d2h_s"), "solver_failures": fails,
+                       "returned": len(res) if res is not None else 0},
+            "roofline": None,
+            "cpu_baseline": finish_cpu_baseline(cpu_proc) if cpu_proc is not None else None,
+        }
+        print(json.dumps(line), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         return cpu_baseline_main(sys.argv[2:])
@@ -255,6 +333,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra (untimed-region) throughput-geometry measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the gather path even with "
                     "one rank (rehearsal of the RCCL code path on a one-GPU box; launch under torch.distributed.run)")
+    ap.add_argument("--workload", default="config1", choices=["config1", "config2"],
+                    help="config1 (default, the driver's line): BASELINE configs[1], --batch simulations PER GPU (weak scaling); "
+                         "config2: BASELINE configs[2], the 4096-simulation grid search through SimulationManager.grid_search / run_all, "
+                         "sharded over the ranks (strong scaling)")
+    ap.add_argument("--results", default="full", choices=["full", "summary"], help="config2: what run_all gathers to rank 0")
+    ap.add_argument("--coeff-sets", type=int, default=256, help="config2: surface coefficient sets (x 16 grid points)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -289,6 +373,8 @@ def main():
     else:
         torch.cuda.set_device(0)
 
+    if args.workload == "config2":
+        return config2_main(args, world, rank, multi, cpu_proc)
     chain = robots.builtin_chain("ur10")
     cfgs = workload_configs(args.batch, args.horizon, args.sim_time, seed=rank, solver=args.solver)
     eng = engine.MpcBatchEngine(local_rank)
@@ -377,6 +463,9 @@ def main():
                    "timed_region": region, "host_bytes_per_pass_MB": d2h_mb,
                    "kernel_steps_per_s": steps_per_pass / avg_kernel_s,
                    "mean_qp_iters_per_step": qp_iters, "qp_iter_histogram_rank0": qp_hist,
+                   "qp_iter_meaning": "Riccati factorisations per MPC step: 1 = the bound-inactive fast path solved the QP outright "
+                                      "(csrc/mpc_ipm.h); otherwise interior-point iterations (+1 for a rejected attempt)",
+                   "fast_path_step_fraction": float((bufs["qp_iter"] == 1).double().mean().item()),
                    "ipm_iterations_per_sec": value * qp_iters, "solver_failures": failures},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -49,7 +49,9 @@ extern "C" {
 #define MPCB_PRECISION_FP64 0          /* everything in fp64 (the reference's arithmetic)                      */
 #define MPCB_PRECISION_FP32_RICCATI 1  /* Riccati factor K, P, R~^-1, p and the three solve sweeps in fp32; iterate,
                                           residuals, right-hand sides, steps and all outputs stay fp64
-                                          (BASELINE.json configs[4]; SQP_RTI on the throughput engine only)     */
+                                          (BASELINE.json configs[4]; SQP_RTI on the throughput engine only).
+                                          An OPT-IN study leg: slower than fp64 at every size measured (-6..-12 %),
+                                          never chosen by mpcb_setup's routing -- only by this field.             */
 
 /* Two kernel families sit behind this ABI: the LATENCY engine (one workgroup of 4-8
  * wavefronts and half or all of a CU's LDS per simulation; batches up to a few simulations per CU, and most SQP runs) and
@@ -61,12 +63,12 @@ extern "C" {
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
  * within a bound derived from the work limit of one chunk -- 4 x chunk steps x SQP iterations x QP iterations x (N+1) x 20 us
  * + 30 s; MPCB_QUEUE_TIMEOUT_S overrides it -- is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
-/* Measured crossovers, N=100, one MI355X (profiles/r03_engine_sweep.txt; latency engine two simulations per CU vs throughput
- * engine, steps/s).  Full SQP, 600 steps: 2560 simulations 256 k vs 229 k, 3072: 265 k vs 265 k, 4096: 289 k vs 321 k;
- * 4096 x 100 steps: 80 k vs 72 k.  SQP_RTI, 600 steps: 1280 simulations 862 k vs 808 k, 1536: 901 k vs 933 k. */
+/* Measured crossovers, N=100, 600 steps, one MI355X, fast path of the QP solve on (profiles/r04_engine_sweep.txt; latency engine two
+ * simulations per CU vs throughput engine, steps/s).  SQP_RTI: 1536 simulations 2.50 M vs 2.19 M, 2048: 2.59 M vs 2.75 M, 4096: 2.67 M vs
+ * 3.18 M.  Full SQP: 2560 simulations 460 k vs 414 k, 4096: 508 k vs 520 k. */
 #define MPCB_STREAM_MIN_BATCH_SQP 3328   /* full SQP: from this many simulations on ... */
 #define MPCB_STREAM_MIN_STEPS_SQP 300    /* ... for runs of at least this many closed-loop steps */
-#define MPCB_STREAM_MIN_BATCH 1408
+#define MPCB_STREAM_MIN_BATCH 1920
 
 typedef struct mpcb_handle mpcb_handle;
 
@@ -96,7 +98,12 @@ typedef struct {
  *   [65] this simulation's prediction horizon, when the simulations of one call have DIFFERENT horizons ("ragged"
  *        batch, e.g. a grid search over prediction_horizon run as one launch): 1 <= [65] <= mpcb_problem.N, and
  *        mpcb_problem.N is the largest of them; 0 means N.  Ragged batches run on the throughput engine.
- *   [66..71] reserved (0)
+ *   [66] bound-inactive fast path of the QP solve (csrc/mpc_ipm.h): 0 = on (the default), 1 = off.  On: a QP whose
+ *        equality-constrained minimiser -- ONE Riccati factorisation -- keeps every bounded component >= 1e-3 inside its bounds is
+ *        solved by that factorisation alone (the solution of the strictly convex QP, lam = 0); every other QP, and every QP when
+ *        off, goes through the HPIPM-style interior-point loop.  `qp_iter` then counts Riccati factorisations.  Not used by the
+ *        fp32-Riccati leg (one fp32 solve is not a solution to qp_tol).
+ *   [67..71] reserved (0)
  * Bounds with |value| >= 1e29 are treated as absent.
  *
  * Kinematic constants, MPCB_NROBOT doubles (what loader.py:24-36 extracts from the URDF):
@@ -115,7 +122,7 @@ typedef struct {
     double *ee_vel;      /* [batch][6][T1]   J_world * qdot              */
     int *status;         /* [batch][Nsim]    acados status 0/1/2/3/4     */
     int *sqp_iter;       /* [batch][Nsim]                                */
-    int *qp_iter;        /* [batch][Nsim]    interior-point iterations   */
+    int *qp_iter;        /* [batch][Nsim]    Riccati factorisations: interior-point iterations (+1 per fast-path attempt) */
     double *residuals;   /* [batch][Nsim][4] stat, eq, ineq, comp        */
     double *cost;        /* [batch][Nsim]                                */
     double *solver_time; /* [batch][Nsim]    device seconds of solver.solve() (simulator.py:209-214,220)  */

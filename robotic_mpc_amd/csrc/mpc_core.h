@@ -293,7 +293,7 @@ struct Engine {
         return NT >= 256 ? (items_per_stage * 106 + NT - 1) / NT : (items_per_stage * 106 + 255) / 256;   // (1-2 wavefronts: more batches instead)
     }
     static constexpr int RS_ROUNDS = rounds_for(12);
-    static constexpr int RS_PER_STAGE = 72 + 6 + 12 + 12;
+    static constexpr int RS_PER_STAGE = RS_PER_STAGE_L;
     MPC_HD ResMap res_map() const
     {
         const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1, pool_n = ex.uni(ex.smem().pool_n);
@@ -369,8 +369,7 @@ struct Engine {
 #else
         // (with half a pool -- two simulations per CU -- segments of 8 x 5 transitions fit, but lose to the streaming sweeps there:
         // batch 512, N = 100: 592 k vs 752 k steps/s; N = 200: 238 k vs 282 k: the segment loads are exposed and short)
-        const ResMap m = seg_map();
-        return ex.uni(RS_GROUPS >= 8 && ex.smem().pool_n >= SEG_POOL_FULL && !resident_ok() && m.scr_n >= (m.T + 1) * 30 + 2 * RS_GROUPS * 12 + 64);
+        return ex.uni(lay_segment_ok(ex.uni(ex.smem().n_hor), ex.uni(ex.smem().pool_n), RS_GROUPS));
 #endif
     }
     MPC_HD bool resident_ok() const
@@ -378,10 +377,7 @@ struct Engine {
 #ifdef MPCB_NO_RESIDENT
         return false;
 #else
-        const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1, pool_n = ex.uni(ex.smem().pool_n);
-        const int scr = pool_n - (NS * RS_PER_STAGE + RS_GROUPS * 144);
-        // scratch: the factorisation's double-buffered chunks (>= 6 stages) ; the corrector's gt (18) + w (12) + slots
-        return ex.uni(scr >= 4096 && scr >= NS * 30 + 2 * RS_GROUPS * 12 + 16);
+        return ex.uni(lay_resident_ok(ex.uni(ex.smem().n_hor), ex.uni(ex.smem().pool_n), RS_GROUPS));
 #endif
     }
     MPC_HD static double gld(const double *p) { return *(MPC_GLOBAL const double *)p; }
@@ -507,6 +503,17 @@ struct Engine {
                         for (int i = 0; i < 12; i++) { xx[i] = gld(g1 + O_X + i); xn[i] = gld(g1 + W1 + O_X + i); }
 #pragma unroll
                         for (int i = 0; i < 6; i++) uu[i] = gld(g1 + O_U + i);
+                        // everything that needs u and x_{k+1} first: the kinematics below want every register (Kin alone is 48
+                        // doubles; the 256-register builds spilled what stayed live across it)
+                        double cu[6];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            const double uj = uu[j], vj = xx[6 + j];
+                            const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
+                            cu[j] = 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
+                            rec[O_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - xn[j];
+                            rec[O_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - xn[6 + j];
+                        }
                         task_lin<true>(rb, P, xx, xx + 6, rec);
                         double s_ = 0.0;
 #pragma unroll
@@ -516,13 +523,7 @@ struct Engine {
                             rec[O_Y + i] = P.w_task[i] * r;
                         }
 #pragma unroll
-                        for (int j = 0; j < 6; j++) {
-                            const double uj = uu[j], vj = xx[6 + j];
-                            const double qdd = P.cq[j] * (uj - vj);  // prediction_model.py:326
-                            s_ += 2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd;
-                            rec[O_BD + j] = (xx[j] + P.a12[j] * vj + P.b1[j] * uj) - xn[j];
-                            rec[O_BD + 6 + j] = (P.a22[j] * vj + P.b2[j] * uj) - xn[6 + j];
-                        }
+                        for (int j = 0; j < 6; j++) s_ += cu[j];
                         csum += 0.5 * P.dt * s_;
                     } else {
 #pragma unroll
@@ -666,6 +667,7 @@ struct Engine {
         const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
         double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2, *const G3 = ex.smem().w.G3;
         double *const Y = ex.pool();   // [NS][6]: y of every stage (5 used)
+        a = ex.uni(a);                 // the step length is the same in every lane: a scalar register pair, not a (spilled) vector one
         typename Ex::template PerLane<double> n_g, n_b, n_d, n_m, n_mu, n_c;
         PROF_T0(tx);
         // ---------------------------------------------------------------- U: 16-byte items (pairs never straddle a field)
@@ -747,16 +749,23 @@ struct Engine {
         ex.barrier();
         PROF_ADD(PF_X1, tx);
         PROF_T0(ty);
+        // y of a stage waits in LDS between its Y and its S items: [stages][6] of the pool.  Horizons whose y does not fit the pool
+        // (N + 1 > pool / 6: beyond ~3 200 stages with a whole CU's pool, ~340 with the smallest) take the phases Y | S,D in stage
+        // ranges of CY stages; everything else is one range, i.e. the code as it was.
+        const int CY = ex.uni(imax(1, imin(ex.smem().pool_n / 6, NS)));
+        for (int y0 = 0; y0 < NS; y0 += CY) {
+        const int y1 = imin(y0 + CY, NS);           // stages [y0, y1)
+        if (y0 > 0) ex.barrier();                   // the S items of the range before are done with Y
         // ---------------------------------------------------------------- Y: items (k < N, i < 5)
         {
             constexpr int R = rounds_for(NTASK);
-            const int items = Nl * NTASK;
+            const int items = (imin(y1, Nl) - y0) * NTASK;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
                     double g[R][12], d[R][12], rr[R];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        const int e = imin(base + r * NT + lane, items - 1), k = e / NTASK, i = e - k * NTASK;
+                        const int e = imax(imin(base + r * NT + lane, items - 1), 0), k = y0 + e / NTASK, i = e - (k - y0) * NTASK;
                         const double *g1 = G1 + (size_t)k * W1 + O_QW, *g2 = G2 + (size_t)k * W2;
                         rr[r] = gld(g2 + O_R + i);
 #pragma unroll
@@ -770,7 +779,7 @@ struct Engine {
                     for (int r = 0; r < R; r++) {
                         const int e = base + r * NT + lane;
                         if (e < items) {
-                            const int k = e / NTASK, i = e - k * NTASK;
+                            const int k = y0 + e / NTASK, i = e - (k - y0) * NTASK;
                             double v = rr[r];
 #pragma unroll
                             for (int j = 0; j < 6; j++) v += g[r][j] * d[r][j];
@@ -779,7 +788,7 @@ struct Engine {
                                 for (int j = 0; j < 6; j++) v += g[r][6 + j] * d[r][6 + j];
                             }
                             v *= P.w_task[i];
-                            Y[k * 6 + i] = v;
+                            Y[(k - y0) * 6 + i] = v;
                             gst(G2 + (size_t)k * W2 + O_Y + i, v);
                         }
                     }
@@ -791,8 +800,10 @@ struct Engine {
         PROF_T0(tz);
         // ---------------------------------------------------------------- S: joint items (k, j < 6), two kinds
         {
-            constexpr int R = rounds_for(6);
-            const int items = NS * 6;
+            // (three joint items per lane and batch -- four wavefronts per simulation -- are 105 operands in flight: with the 256
+            // registers of the two-simulations-per-CU build that spilled ten of them; two there, the other simulation covers the latency)
+            constexpr int R = Ex::VGPR_BUDGET <= 256 && rounds_for(6) > 2 ? 2 : rounds_for(6);
+            const int items = (y1 - y0) * 6;
             const double dt = P.dt, lm = P.lm;
             // bound part of a bounded component ci (value `val`, step `dv`): returns gt, updates rg, writes rd | rm | Gamma
             auto bounds = [&](int lane, int k, int ci, double val_, double dv, double l_lo, double l_hi, double t_lo, double t_hi,
@@ -824,13 +835,13 @@ struct Engine {
             };
             // ---- one phase: the operands of the u/v items, the q items and the dynamics items of a batch all in flight first
             constexpr int RD = 2 * R;                 // twice as many dynamics items (12 per stage) as joint items (6)
-            const int items_d = NS * NX;
+            const int items_d = (y1 - y0) * NX;
             for (int base = 0; base < items; base += R * NT) {
                 ex.wpar([&](int lane) {
                     double v[R][12], q[R][13], d[RD][5];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        const int e = imin(base + r * NT + lane, items - 1), k = e / 6, j = e - k * 6, km = imax(k - 1, 0);
+                        const int e = imin(base + r * NT + lane, items - 1), k = y0 + e / 6, j = e - (k - y0) * 6, km = imax(k - 1, 0);
                         const double *g1 = G1 + (size_t)k * W1, *g2 = G2 + (size_t)k * W2, *gm = G1 + (size_t)km * W1;
                         v[r][0] = gld(g1 + O_U + j);      v[r][1] = gld(g1 + O_X + 6 + j);
                         v[r][2] = gld(g1 + O_QW + j);     v[r][3] = gld(g1 + O_QW + 12 + j);
@@ -848,7 +859,7 @@ struct Engine {
                     }
 #pragma unroll
                     for (int r = 0; r < RD; r++) {
-                        const int e = imin(2 * base + r * NT + lane, items_d - 1), k = e / NX, i = e - k * NX, kn = imin(k + 1, Nl);
+                        const int e = imin(2 * base + r * NT + lane, items_d - 1), k = y0 + e / NX, i = e - (k - y0) * NX, kn = imin(k + 1, Nl);
                         const double *dw = G1 + (size_t)k * W1 + O_QW;
                         d[r][0] = gld(dw + 6 + i);
                         d[r][1] = gld(dw + (i < 6 ? 12 + i : i - 6));
@@ -861,7 +872,7 @@ struct Engine {
                     for (int r = 0; r < R; r++) {
                         const int e = base + r * NT + lane;
                         if (e < items) {
-                            const int k = e / 6, j = e - k * 6;
+                            const int k = y0 + e / 6, j = e - (k - y0) * 6;
                             const double du = v[r][2], dvv = v[r][3];
                             const double uj = v[r][0] + du, vj = v[r][1] + dvv;
                             const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
@@ -879,7 +890,7 @@ struct Engine {
                             double rgv = 0.0;
                             if (k >= 1) {
                                 if (k < Nl) {
-                                    rgv = dt * (v[r][7] * Y[k * 6 + 4] + c2 * (vj - uj));
+                                    rgv = dt * (v[r][7] * Y[(k - y0) * 6 + 4] + c2 * (vj - uj));
                                     rgv += P.a12[j] * v[r][4] + P.a22[j] * v[r][5];
                                 }
                                 rgv += (k < Nl ? dt : 1.0) * lm * dvv;
@@ -893,7 +904,7 @@ struct Engine {
                                 if (k < Nl) {
                                     double s_ = 0.0;
 #pragma unroll
-                                    for (int i = 0; i < NTASK; i++) s_ += q[r][2 + i] * Y[k * 6 + i];
+                                    for (int i = 0; i < NTASK; i++) s_ += q[r][2 + i] * Y[(k - y0) * 6 + i];
                                     rg = dt * s_ + q[r][7];
                                 }
                                 rg += (k < Nl ? dt : 1.0) * lm * dq;
@@ -909,7 +920,7 @@ struct Engine {
                     for (int r = 0; r < RD; r++) {
                         const int e = 2 * base + r * NT + lane;
                         if (e < items_d && e < 2 * (base + R * NT)) {
-                            const int k = e / NX, i = e - k * NX;
+                            const int k = y0 + e / NX, i = e - (k - y0) * NX;
                             double vv = 0.0;
                             if (k < Nl) {
                                 if (i < 6) vv = d[r][0] + P.a12[i] * d[r][1] + P.b1[i] * d[r][2];
@@ -924,6 +935,7 @@ struct Engine {
             }
         }
         PROF_ADD(PF_X3, tz);
+        }   // stage ranges
         ex.par([&](int lane) {
             ex.put_max(sm.red[0], lane, n_g.at(lane)); ex.put_max(sm.red[1], lane, n_b.at(lane));
             ex.put_max(sm.red[2], lane, n_d.at(lane)); ex.put_max(sm.red[3], lane, n_m.at(lane));

@@ -42,6 +42,7 @@ extern __shared__ __attribute__((aligned(16))) double g_pool[];
 template <int NWV, int WPE = 1>
 struct DevExec {
     static constexpr int NT = WAVE * NWV;
+    static constexpr int VGPR_BUDGET = (WPE >= 2 || NWV > 4) ? 256 : 512;   // registers per lane this variant is compiled for (two wavefronts per SIMD: 256)
     __device__ __forceinline__ static int lane_id() { return (int)threadIdx.x; }
     __device__ __forceinline__ Smem &smem() const { return g_sm; }
     __device__ __forceinline__ double *pool() const { return g_pool; }
@@ -628,12 +629,12 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
         // chunk-parallel then, and a second wavefront per SIMD buys issue slots (665 k vs 651 k steps/s on configs[1]); the streaming
         // path's role layout prefers 4 (round 1).
         {
-            const int NS = p->N + 1, scr = h->pool_doubles - (NS * 102 + 16 * 144);
+            // (the device's own predicates, mpc_layout.h; 16 lane groups at four and at eight wavefronts)
             // (measured: N = 100 665 k vs 651 k; N = 50 1.045 M vs 1.054 M; N = 20 1.59 M vs 1.68 M -- short horizons have too few items)
-            const bool resident = scr >= 4096 && scr >= NS * 30 + 2 * 16 * 12 + 16;
+            const bool resident = lay_resident_ok(p->N, h->pool_doubles, 16);
             // longer horizons at one simulation per CU run the same sweeps one LDS segment at a time (Engine::segment_ok): eight
             // wavefronts there as well (batch 256, N = 200: 244.8 k vs 234.5 k steps/s; N = 300: 144.5 k vs 137.9 k)
-            const bool segments = !resident && h->pool_doubles >= SEG_POOL_FULL;
+            const bool segments = lay_segment_ok(p->N, h->pool_doubles, 16);
             if (wpc == 1 && p->N >= 80 && (resident || segments)) nw = 8;
         }
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }

@@ -143,6 +143,11 @@ MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, cons
         const V3 ds = dvl + cross(dom, tw) + cross(om, dtw);
         rec_g[O_GQ + 4 * 6 + i] = dot(dyh, s) + dot(yh, ds);
         rec_g[O_GV + i] = dot(yh, cj[i] + cross(zi, tw));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one Jacobian column at a time: left alone, the scheduler interleaves all six (each ~100 independent operations) and the
+        // 256-register builds spill ~60 values around this loop
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 

@@ -144,6 +144,23 @@ struct Ws {
 // Segment geometry by pool size: a whole CU's pool holds 16 chunks of 7 transitions, half a pool (two simulations per CU) 8 chunks of 5.
 constexpr int SEG_L_FULL = 7, SEG_J_FULL = 16, SEG_L_HALF = 5, SEG_J_HALF = 8, SEG_POOL_FULL = 17000;
 MPC_HD size_t ws_phi_doubles(int N) { return (size_t)((N + SEG_L_HALF - 1) / SEG_L_HALF + 1) * 144; }
+// Residency predicates of the latency engine -- ONE formula for the device (Engine::resident_ok / segment_ok) and for mpcb_setup's choice
+// of the launch geometry: per stage the solve sweeps keep K (72) | R~^-1 h_u (6) | e (12) | p (12) in LDS, plus one 12x12
+// chunk transition matrix per lane group (`groups` = min(lanes / 16, 16)); the rest of the pool is scratch.
+constexpr int RS_PER_STAGE_L = 72 + 6 + 12 + 12;
+MPC_HD bool lay_resident_ok(int N, int pool_n, int groups)
+{
+    const int NS = N + 1, scr = pool_n - (NS * RS_PER_STAGE_L + groups * 144);
+    // scratch: the factorisation's double-buffered chunks (>= 6 stages) ; the corrector's gt (18) + w (12) + slots
+    return scr >= 4096 && scr >= NS * 30 + 2 * groups * 12 + 16;
+}
+MPC_HD bool lay_segment_ok(int N, int pool_n, int groups)
+{
+    if (groups < 8 || pool_n < SEG_POOL_FULL || lay_resident_ok(N, pool_n, groups)) return false;
+    const int Jc = groups < SEG_J_FULL ? groups : SEG_J_FULL, T = SEG_L_FULL * Jc;
+    const int scr = pool_n - ((T + 1) * RS_PER_STAGE_L + Jc * 144);
+    return scr >= (T + 1) * 30 + 2 * groups * 12 + 64;
+}
 
 // offset of entry (r, c), r <= c, of a symmetric 12x12 matrix stored as its upper triangle by rows
 MPC_HD int tri(int r, int c) { return r * 12 - (r * (r - 1)) / 2 + (c - r); }

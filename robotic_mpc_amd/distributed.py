@@ -188,7 +188,13 @@ def agree_ok(check=None, error: Optional[BaseException] = None) -> None:
         on_device = d.get_backend() == "nccl"
         flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
                             device=torch.device("cuda", local_device()) if on_device else torch.device("cpu"))
-        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        try:
+            d.all_reduce(flag, op=d.ReduceOp.MIN)
+        except Exception:   # noqa: BLE001
+            # after a sticky HIP error on this device the collective itself throws: what the caller needs is the original failure
+            if err is not None:
+                raise err
+            raise
         if int(flag.item()) == 0 and err is None:
             raise RuntimeError(f"rank {d.get_rank()}: another rank failed before the results gather; stopping with it")
     if err is not None:
@@ -237,10 +243,12 @@ def to_host(v, out=None) -> np.ndarray:
 
 
 def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Callable, use_dist: bool,
-                    info: Optional[Dict] = None) -> Optional[List[Dict[str, np.ndarray]]]:
+                    info: Optional[Dict] = None, only: Optional[Sequence[str]] = None) -> Optional[List[Dict[str, np.ndarray]]]:
     """Run all simulations bucket by bucket (sharded when ``use_dist``) and return one record per
     simulation in queue order (rank 0; None on other ranks).  ``info`` (optional dict) receives
-    ``kernel_ms`` (sum over the launches of this rank) and ``d2h_s`` (device -> host copy time)."""
+    ``kernel_ms`` (sum over the launches of this rank) and ``d2h_s`` (device -> host copy time).
+    ``only``: names of the arrays that leave the device -- ``("summary",)`` is the summary-only mode of SURVEY 8(e): 24 doubles
+    per simulation are gathered / copied instead of the 14 result arrays (~262 KB per simulation at 600 steps)."""
     import time
 
     ws, me = (world_size(), rank()) if use_dist else (1, 0)
@@ -293,10 +301,15 @@ def run_partitioned(resolved: Sequence[Dict], runner: Callable, chain_for: Calla
             elif "summary" not in local:
                 local = dict(local)
                 local["summary"] = _host_summary(local, mine)
+            if only is not None:
+                local = {k: local[k] for k in only}
             full = gather_to_root(local, [b[1] - b[0] for b in bounds])
         else:
-            full = {k: to_host(v) for k, v in local.items()}
-            if "summary" not in full:
+            if only is not None and "summary" in only and "summary" not in local:
+                local = dict(local)
+                local["summary"] = _host_summary(local, mine)
+            full = {k: to_host(v) for k, v in local.items() if only is None or k in only}
+            if "summary" not in full and only is None:
                 full["summary"] = _host_summary(full, mine)
         d2h_s += time.perf_counter() - t0
         if me == 0:

@@ -136,6 +136,12 @@ class Simulator:
         bucket are fine).  ``rec`` may carry ``errors`` [7, T1] (logged on the device with every column) and
         ``summary`` [24] (mpcb_summary); what is missing is computed on demand from the logs."""
         self._invalidate_cache()
+        if "z" not in rec:
+            # summary-only result (run_all(results="summary")): the 24-scalar record of mpcb_summary and nothing else left the
+            # device; get_summary() / metrics work, the logs and everything derived from them do not exist on the host
+            self._summary_row = rec["summary"]
+            self._summary_only = True
+            return
         self.simulation_model = _PlantLog(rec["z"], rec["u"], rec["ee_pose"], rec["ee_rpy"], rec["ee_vel"], self.dt)
         self.sqp_iter = rec["sqp_iter"]
         self.qp_iter = rec["qp_iter"]
@@ -158,6 +164,10 @@ class Simulator:
             self.__dict__.pop(attr, None)
 
     def _need_run(self, what):
+        if getattr(self, "_summary_only", False):
+            if what in ("summary", "metrics"):
+                return
+            raise RuntimeError(f"{what} needs the logs: this simulation was run with results='summary' (only the summary left the GPU)")
         if not self._data_computed:
             raise RuntimeError(f"Must call run() before accessing {what}")
 
@@ -237,16 +247,20 @@ class _ResultItem(dict):
 
     def __init__(self, name, sim):
         super().__init__(name=name, simulator=sim)
+        # a summary-only result (run_all(results="summary")) has no logs to derive 'data' / 'analysis' from
+        self._lazy = {"summary": "get_summary"} if getattr(sim, "_summary_only", False) else self._LAZY
 
     def __missing__(self, key):
-        if key in self._LAZY:
-            v = getattr(dict.__getitem__(self, "simulator"), self._LAZY[key])()
+        if key in self._lazy:
+            v = getattr(dict.__getitem__(self, "simulator"), self._lazy[key])()
             dict.__setitem__(self, key, v)
             return v
+        if key in self._LAZY:
+            raise RuntimeError(f"'{key}' needs the logs: this run kept results='summary' (only the summaries left the GPU)")
         raise KeyError(key)
 
     def _fill(self):
-        for k in self._LAZY:
+        for k in self._lazy:
             self[k]
 
     def get(self, key, default=None):
@@ -256,13 +270,13 @@ class _ResultItem(dict):
             return default
 
     def __contains__(self, key):
-        return key in self._LAZY or dict.__contains__(self, key)
+        return key in self._lazy or dict.__contains__(self, key)
 
     def keys(self): self._fill(); return dict.keys(self)
     def items(self): self._fill(); return dict.items(self)
     def values(self): self._fill(); return dict.values(self)
     def __iter__(self): self._fill(); return dict.__iter__(self)
-    def __len__(self): return 5
+    def __len__(self): return 2 + len(self._lazy)
 
 
 # a runner maps (list of resolved configs of one bucket, chain) -> dict of arrays [batch, ...]
@@ -406,12 +420,19 @@ class SimulationManager:
             dev = local_device()
         return _EngineRunner(dev)
 
-    def run_all(self, return_results=True, distributed: Optional[bool] = None, checkpoint: Optional[str] = None):
+    def run_all(self, return_results=True, distributed: Optional[bool] = None, checkpoint: Optional[str] = None,
+                results: str = "full"):
         """Run every queued simulation (simulator.py:641-676).
 
         Returns the reference's list of ``{'name','simulator','data','analysis','summary'}``
         dicts, in queue order.  Under ``torch.distributed`` (world_size > 1) every rank must
         call this with the same queue; the full list is returned on rank 0 and ``[]`` elsewhere.
+
+        ``results="summary"`` (extension): only the 21-scalar summary of every simulation
+        (``get_summary()``, reduced on the device) is gathered and copied to the host -- 192 B per simulation
+        instead of ~262 KB of logs; the items then carry 'name', 'simulator' and 'summary', and asking one for
+        'data' / 'analysis' raises.  ``return_results=False`` without a ``checkpoint`` moves the summaries only
+        as well (there is nobody to hand the logs to); they stay available as ``self.last_summaries``.
 
         ``checkpoint`` (extension): path of a results archive (results_io).
         Simulations already in it -- same name and same config -- are not run again; the archive
@@ -439,7 +460,13 @@ class SimulationManager:
         todo = [i for i in range(len(sims)) if i not in done]
         info: Dict[str, Any] = {}
         t_run = time.time()
-        new = dmod.run_partitioned([resolved[i] for i in todo], runner, chain_for, use_dist, info) if todo else []
+        if results not in ("full", "summary"):
+            raise ValueError("results must be 'full' or 'summary'")
+        if results == "summary" and checkpoint:
+            raise ValueError("a checkpoint archive stores the logs: use results='full' with checkpoint")
+        summary_only = results == "summary" or (not return_results and not checkpoint)
+        new = dmod.run_partitioned([resolved[i] for i in todo], runner, chain_for, use_dist, info,
+                                   only=("summary",) if summary_only else None) if todo else []
         self.last_run_info = {"n_sims": len(sims), "n_resumed": len(done), "setup_s": t_run - t_start,
                               "run_s": time.time() - t_run, "kernel_ms": info.get("kernel_ms", 0.0),
                               "d2h_s": info.get("d2h_s", 0.0),
@@ -464,10 +491,12 @@ class SimulationManager:
                         names.append(str(arch["names"][j])); configs.append(json.loads(str(arch["configs"][j])))
                         recs.append(results_io.record_at(arch, j))
             results_io.save_results(checkpoint, names, configs, recs)
-        results = []
+        out = []
         for sim, rec in zip(sims, records):
             sim._attach(rec)
             if return_results:
-                results.append(_ResultItem(sim.name, sim))
+                out.append(_ResultItem(sim.name, sim))
+        self.last_summaries = [{"name": sim.name, **sim.get_summary()} for sim in sims]
         self.last_run_info["wall_s"] = time.time() - t_start
-        return results if return_results else None
+        self.last_run_info["results"] = "summary" if summary_only else "full"
+        return out if return_results else None

@@ -191,18 +191,27 @@ def reference_errors_loop(ee_pose, ee_vel, coeffs, t_ee, px_ref, vy_ref):
 
 def random_parameter_cfgs(n, seed, **kw):
     """Seeded random draws over every per-simulation parameter of the parameter record: weights, references, surface, bandwidths,
-    start state, integrator, and bounds from wide to tight (some active from the first step)."""
+    start state, integrator, bounds from wide to tight (some active from the first step), and the sampling time dt (slot [0]:
+    5e-4 .. 0.02, i.e. wcv * dt from 0.03 to 2.4 -- the reference's own regime is dt = 5e-4, main.py:14).  `simulation_time` in
+    `kw` is read as a number of steps at dt = 0.01: every simulation of the returned list runs that many steps (Nsim is a
+    property of the launch, dt of the simulation)."""
     from robotic_mpc_amd import config
 
     rng = np.random.default_rng(seed)
+    steps = int(round(float(kw.pop("simulation_time", config.BASE_PARAMS["simulation_time"])) / 0.01))
     out = []
     for i in range(n):
         tight = rng.uniform(0.6, 3.2)
-        out.append(config.resolve_config(config.base_params(
+        p = dict(
             q_0=config.BASE_PARAMS["q_0"] + rng.uniform(-0.15, 0.15, 6), qdot_0=rng.uniform(-0.5, 0.5, 6),
             wcv=rng.uniform(60.0, 250.0, 6), w_u=float(10 ** rng.uniform(-3, -1.5)), w_qddot=float(10 ** rng.uniform(-2.3, -1)),
             px_ref=float(rng.uniform(0.3, 0.55)), vy_ref=float(rng.uniform(-0.05, 0.08)),
             surface_coeffs={k: float(v) for k, v in zip("abcdef", rng.normal([-0.1, 0.1, -0.01, 0.01, 0.01, 0.0], 0.03))},
             qdot_min=np.full(6, -tight), qdot_max=np.full(6, tight),
-            integration_method=["RK4", "RK4", "Euler", "RK2", "RK3"][int(rng.integers(5))], **kw)))
+            integration_method=["RK4", "RK4", "Euler", "RK2", "RK3"][int(rng.integers(5))])
+        dt = [5e-4, 2e-3, 0.01, 0.01, 0.02][int(rng.integers(5))]
+        # the plant integrators are stable for wcv * dt < 2 (Euler) .. 2.785 (RK4): keep wcv * dt <= 1.9 at the coarse steps
+        p["wcv"] = np.minimum(p["wcv"], (1.9 if p["integration_method"] == "Euler" else 2.4) / dt)
+        out.append(config.resolve_config(config.base_params(dt=dt, simulation_time=(steps + 0.5) * dt, **p, **kw)))
+        assert out[-1]["Nsim"] == steps
     return out

@@ -44,14 +44,14 @@ def test_version_and_sizes(lib):
 
 def test_engine_selection_thresholds(lib, monkeypatch):
     """mpcb_engine_for (host logic, no device): which kernel family a uniform bucket goes to, at both sides of every measured
-    crossover of include/mpcbatch.h (profiles/r03_engine_sweep.txt), and the MPCB_ENGINE override."""
+    crossover of include/mpcbatch.h (profiles/r04_engine_sweep.txt), and the MPCB_ENGINE override."""
     from robotic_mpc_amd import engine
 
     monkeypatch.delenv("MPCB_ENGINE", raising=False)
     hdr = open(os.path.join(ROOT, "include", "mpcbatch.h")).read()
     rti, sqp, steps = (int(re.search(r"#define %s\s+(\d+)" % n, hdr).group(1))
                        for n in ("MPCB_STREAM_MIN_BATCH", "MPCB_STREAM_MIN_BATCH_SQP", "MPCB_STREAM_MIN_STEPS_SQP"))
-    assert (rti, sqp, steps) == (1408, 3328, 300)
+    assert (rti, sqp, steps) == (1920, 3328, 300)
     for batch, N, nsim, solver, prec, want in (
             (256, 100, 600, "SQP_RTI", 0, 0), (rti - 1, 100, 600, "SQP_RTI", 0, 0), (rti, 100, 600, "SQP_RTI", 0, 1),
             (4096, 100, 600, "SQP_RTI", 0, 1), (64, 300, 150, "SQP_RTI", 1, 1),          # fp32 Riccati: throughput engine only

@@ -42,7 +42,21 @@ def _worker(rank, world, port, outdir):
                     assert np.array_equal(a["data"][k], b["data"][k]), (a["name"], k)
                 assert a["summary"]["weighted_rmse"] == b["summary"]["weighted_rmse"]
             assert m.last_run_info["world_size"] == 1
+            # summary-only gather: only the 24-scalar records cross the ranks; same summaries, no logs on the host
             open(os.path.join(outdir, "ok"), "w").write("ok")
+        lite = m.run_all(distributed=True, results="summary")
+        assert m.run_all(distributed=True, return_results=False) is None
+        if rank == 0:
+            assert m.last_run_info["results"] == "summary" and len(m.last_summaries) == 7
+            for a, b, c in zip(lite, single, m.last_summaries):
+                assert a["name"] == b["name"] == c["name"] and set(a.keys()) == {"name", "simulator", "summary"}
+                for k, v in b["summary"].items():
+                    if "time" not in k:      # (wall-clock fields differ run to run)
+                        assert a["summary"][k] == v and c[k] == v, k
+                assert a["simulator"].simulation_model is None
+                with pytest.raises(RuntimeError, match="summary"):
+                    a["data"]
+            open(os.path.join(outdir, "ok_summary"), "w").write("ok")
         else:
             assert res == []
     finally:
@@ -56,7 +70,7 @@ def test_two_rank_gloo_sharded_equals_single(tmp_path, orc):
 
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok").exists()
+    assert (tmp_path / "ok").exists() and (tmp_path / "ok_summary").exists()
 
 
 # ------------------------------------------------------------------------------------------- 8 ranks

@@ -33,11 +33,15 @@ def _cfg(**kw):
     # horizons beyond the LDS-resident limit with the whole pool: SEGMENT-resident sweeps (2 and 3 segments, a segment of exactly SEG_T)
     (224, 0.04, "SQP_RTI", 0, 0, 8), (300, 0.03, "SQP_RTI", 0, 0, 4), (126, 0.04, "SQP", 0, 0, 4),
     # half a CU's pool (two simulations per CU on the device), four wavefronts: one and two segments of the register-resident sweeps
-    (100, 0.05, "SQP_RTI", 0, 9156, 4), (130, 0.03, "SQP", 0, 9156, 4), (7, 0.05, "SQP", 0, 9156, 4)])
+    (100, 0.05, "SQP_RTI", 0, 9156, 4), (130, 0.03, "SQP", 0, 9156, 4), (7, 0.05, "SQP", 0, 9156, 4),
+    # a horizon whose y (6 doubles per stage) does not fit the smallest pool: the residual pass takes its Y | S,D phases in two stage
+    # ranges (401 x 6 > 2048); interior-point loop (qp_fast_path off) and fast path
+    (400, 0.02, "SQP_RTI", 0, 2048, 4), (400, 0.02, "SQP_RTI_IPM", 0, 2048, 4)])
 def test_emulated_engine_matches_oracle(orc, ur10, ur10_rb, N, T, solver, chunk, pool, waves):
     import emu
 
-    cfg = _cfg(prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver})
+    ipm_only = solver.endswith("_IPM")
+    cfg = _cfg(prediction_horizon=N, simulation_time=T, solver_options={"nlp_solver_type": solver.replace("_IPM", "")}, qp_fast_path=not ipm_only)
     ref = orc.run(ur10_rb, orc.make_params(cfg))
     out = emu.run([cfg], ur10, step_chunk=chunk, pool_doubles=pool, waves=waves)
     for k in ("z", "u", "ee_pose", "ee_rpy", "ee_vel"):

@@ -556,3 +556,29 @@ def test_ragged_problem_construction():
     s5 = config.resolve_config({**_base(), "prediction_horizon": 5, "solver_options": {"nlp_solver_type": "SQP"}})
     with pytest.raises(ValueError, match="SQP_RTI"):
         engine.make_problem([s, s5])
+
+
+def test_run_all_summary_only_mode_moves_the_summaries_alone(ur10):
+    """with results='summary' (or return_results=False) only the per-simulation summary record leaves the runner's
+    buffers -- the analogue of gathering 192 B instead of ~262 KB per simulation across the GPUs; simulator.py:641-676 keeps the
+    list shape, the items carry name / simulator / summary."""
+    import helpers as hp
+    from robotic_mpc_amd import SimulationManager, base_params, distributed as dmod
+
+    m = SimulationManager(base_params(prediction_horizon=4, simulation_time=0.05), runner=hp.oracle_runner)
+    m.sweep("w_qddot", [0.02, 0.05, 0.08])
+    full = m.run_all()
+    lite = m.run_all(results="summary")
+    recs = dmod.run_partitioned([r["simulator"].resolved for r in full], hp.oracle_runner, lambda c: ur10, False, only=("summary",))
+    assert all(set(r) == {"summary"} and r["summary"].shape == (24,) for r in recs)     # nothing with a time axis comes back
+    assert [r["name"] for r in lite] == [r["name"] for r in full]
+    for a, b in zip(lite, full):
+        same = lambda x, y: all(x[k] == y[k] for k in x if "time" not in k) and set(x) == set(y)     # (wall-clock fields differ run to run)
+        assert same(a["summary"], b["summary"]) and len(a) == 3 and "data" not in a and a["simulator"].simulation_model is None
+        assert a["simulator"].metrics["weighted_rmse"] == b["summary"]["weighted_rmse"]
+        with pytest.raises(RuntimeError, match="results='summary'"):
+            a["simulator"].errors
+    assert m.run_all(return_results=False) is None and m.last_run_info["results"] == "summary"
+    assert [s["weighted_rmse"] for s in m.last_summaries] == [r["summary"]["weighted_rmse"] for r in full]
+    with pytest.raises(ValueError):
+        m.run_all(results="summary", checkpoint="/tmp/never_written.npz")
