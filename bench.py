@@ -416,13 +416,22 @@ def main():
     barrier()
     kernel_ms = []
     host = None
+    pass_ms = []
+    # (like timeit: no cyclic garbage collection inside the timed region -- a generation-2 sweep of this interpreter, torch loaded, is
+    # ~40 ms, 40 % of a pass, and whether one lands inside the three timed passes depends on how many objects the imports created)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        tp = time.perf_counter()
         host = None                        # (frees the previous pass's pinned arrays before the next ones are taken)
         host = one_pass()
         kernel_ms.append(eng.kernel_ms())  # HIP events on the launch stream (the pass has already waited for the kernel,
+        pass_ms.append((time.perf_counter() - tp) * 1e3)
     barrier()                              # except with --kernel-only, where this wait is the only sync)
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -461,7 +470,7 @@ def main():
                    "batch_per_gpu": args.batch, "horizon": pb.N, "closed_loop_steps": pb.Nsim, "solver": args.solver,
                    "parallelism": f"{world} GPU x {args.batch} workgroups (one simulation each) x {geo['waves_per_sim']} wavefronts",
                    "timed_region": region, "host_bytes_per_pass_MB": d2h_mb,
-                   "kernel_steps_per_s": steps_per_pass / avg_kernel_s,
+                   "kernel_steps_per_s": steps_per_pass / avg_kernel_s, "pass_ms_rank0": pass_ms, "kernel_ms_rank0": kernel_ms,
                    "mean_qp_iters_per_step": qp_iters, "qp_iter_histogram_rank0": qp_hist,
                    "qp_iter_meaning": "Riccati factorisations per MPC step: 1 = the bound-inactive fast path solved the QP outright "
                                       "(csrc/mpc_ipm.h); otherwise interior-point iterations (+1 for a rejected attempt)",

@@ -395,16 +395,21 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
-    constexpr int I_D = 96, I_L = 174;                       // input image: G1 row | D | lin
+    // FAST modes stream less (round 4): no Newton step comes in (dw = 0: G1 row | lin, 156 doubles) and neither the QP iterate
+    // (untouched) nor the residual records rg | rd | rm (nobody reads them on the fast path) go out: [R, Y(, BD)] | [GAM | GT | RB].
+    constexpr int I_D = 96, I_L = FASTM ? 96 : 174;          // input image: G1 row | D | lin   (FAST: G1 row | lin)
+    constexpr int IN_ITEMS = FASTM ? 78 : 117;
     constexpr int RYW = FUSE ? O_BD + 12 : 10;               // G2 columns written from 0: [R, Y] or [R, Y, pad, BD]
-    constexpr int O_W = 0, O_RY = 78, O_G = O_RY + RYW, O_3 = O_G + 42;   // output image
-    Bundle<2, 117> bin;
-    Bundle<2, (78 + RYW + 42 + 66) / 2> bout;
+    constexpr int O_W = 0, O_RY = FASTM ? 0 : 78, O_G = O_RY + RYW, O_3 = O_G + 42;   // output image
+    constexpr int OUT_ITEMS = FASTM ? (RYW + 42) / 2 : (78 + RYW + 42 + 66) / 2;
+    constexpr int OUT_NI = (OUT_ITEMS + WAVE - 1) / WAVE;
+    Bundle<2, IN_ITEMS> bin;
+    Bundle<OUT_NI, OUT_ITEMS> bout;
     {
-        const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G3, w.ld, O_DW, 78), segd(w.G2, w.ld, 0, W2_LIN)};
-        bin.setup(si, lane);
-        const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, RYW), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)};
-        bout.setup(so, lane);
+        if (FASTM) { const Seg si[2] = {segd(w.G1, w.ld, 0, W1), segd(w.G2, w.ld, 0, W2_LIN)}; bin.setup(si, lane); }
+        else { const Seg si[3] = {segd(w.G1, w.ld, 0, W1), segd(w.G3, w.ld, O_DW, 78), segd(w.G2, w.ld, 0, W2_LIN)}; bin.setup(si, lane); }
+        if (FASTM) { const Seg so[2] = {segd(w.G2, w.ld, 0, RYW), segd(w.G2, w.ld, O_GAM, 42)}; bout.setup(so, lane); }
+        else { const Seg so[4] = {segd(w.G1, w.ld, O_QW, 78), segd(w.G2, w.ld, 0, RYW), segd(w.G2, w.ld, O_GAM, 42), segd(w.G3, w.ld, 0, 66)}; bout.setup(so, lane); }
         bout.seek(0, 1);
     }
     double a_g = 0, a_b = 0, a_d = 0, a_m = 0, a_mu = 0, ncl = 0;
@@ -520,7 +525,7 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
         }
     };
     if (lane < NX) sm.vec[0][lane] = 0.0;      // pi_{-1}: never read (k = 0 rows return early)
-    sweep<117, 2, false>(bin, N, lane, [&](int k, double *cur, double *nxt, double *) {
+    sweep<IN_ITEMS, OUT_NI, false>(bin, N, lane, [&](int k, double *cur, double *nxt, double *) {
         double *o = sm.out[k & 1];
 #ifdef MPCB_NOCOMPUTE
         (void)cur; (void)nxt; store_out(bout, o, lane); return;
@@ -706,11 +711,13 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
                     gt = bhi ? gt - (rmu + l_hi * rdu) * it_hi : gt;
                     a_mu = bhi ? a_mu + rmu : a_mu;
                     a_d = fmax(a_d, fabs(rdu)); a_m = fmax(a_m, fabs(rmu));
-                    o[O_3 + O_RD + ci] = rdl; o[O_3 + O_RD + 12 + ci] = rdu;
-                    o[O_3 + O_RM + ci] = rml; o[O_3 + O_RM + 12 + ci] = rmu;
+                    if (!FASTM) {
+                        o[O_3 + O_RD + ci] = rdl; o[O_3 + O_RD + 12 + ci] = rdu;
+                        o[O_3 + O_RM + ci] = rml; o[O_3 + O_RM + 12 + ci] = rmu;
+                    }
                     o[O_G + ci] = gam;
                 }
-                o[O_3 + O_RG + ci] = rg;
+                if (!FASTM) o[O_3 + O_RG + ci] = rg;
                 o[O_G + 12 + ci] = gt;
                 a_g = fmax(a_g, fabs(rg));
             } else if (lane < 30) {
@@ -726,9 +733,11 @@ SE_PASS IpmNorms residual_pass(double a, double *nlp_out = nullptr)
             } else if (lane >= 32) {
                 // the updated QW..QT of this stage and r, y go out with the residual records (39 + 5 items, two per lane
                 // where needed; MODE 2: BD was put there by its lanes); lanes 48..59: pi_k for the next stage
-                ((MPC_LOCAL D2 *)(o + O_W))[lc] = c1;
-                if (lc < 7) ((MPC_LOCAL D2 *)(o + O_W))[32 + lc] = c2;
-                else if (lc < 12) ((MPC_LOCAL D2 *)(o + O_RY))[lc - 7] = c2;
+                if (!FASTM) {
+                    ((MPC_LOCAL D2 *)(o + O_W))[lc] = c1;
+                    if (lc < 7) ((MPC_LOCAL D2 *)(o + O_W))[32 + lc] = c2;
+                }
+                if (lc >= 7 && lc < 12) ((MPC_LOCAL D2 *)(o + O_RY))[lc - 7] = c2;
                 if (lane >= 48 && lane < 60) sm.vec[(k + 1) & 1][lane - 48] = q_a;
             }
         }
@@ -1013,7 +1022,8 @@ struct FactLane {
     int a, b, oqq, oqv, ovv;
 };
 
-template <class FT>
+// FASTF (fast path): the record goes out without its tail [w | R~^-1] -- only the corrector reads that (48 of 232 scalars).
+template <class FT, bool FASTF = false>
 SE_PASS void fact_pass()
 {
     SSmem &sm = g_ssm;
@@ -1021,13 +1031,14 @@ SE_PASS void fact_pass()
     const int lane = threadIdx.x;
     const int N = uni(sm.n_hor);
     const SWs w = sm.w;
-    constexpr int NIO = ni_of(SW4 * (int)sizeof(FT));
+    constexpr int SOUT = FASTF ? SW4_FWD : SW4;
+    constexpr int NIO = ni_of(SOUT * (int)sizeof(FT));
     Bundle<1, 39> bin;
-    Bundle<NIO, SW4 * (int)sizeof(FT) / 16> bout;
+    Bundle<NIO, SOUT * (int)sizeof(FT) / 16> bout;
     {
         const Seg si[1] = {segd(w.G2, w.ld, O_GQ, 78)};
         bin.setup(si, lane);
-        const Seg so[1] = {segf<FT>(w.G4, w.ld, 0, SW4)};
+        const Seg so[1] = {segf<FT>(w.G4, w.ld, 0, SOUT)};
         bout.setup(so, lane);
         bout.seek(N, -1);
     }
@@ -1264,15 +1275,15 @@ SE_PASS StepInfo forward_pass()
     const SWs w = sm.w;
     constexpr int LF = AFFINE ? SW4_AFF : SW4_FWD;
     constexpr int FB = LF * (int)sizeof(FT);                       // bytes of the factor part
-    constexpr int ITEMS = (FB + 96 * 8) / 16;
-    constexpr int NII = ni_of(FB + 96 * 8);
-    constexpr int I_LT = FB / 8, I_R = I_LT + 48;                  // doubles
+    constexpr int REST = FAST ? 18 : 96;                           // doubles behind the factor: [QLAM, QT | RD, RM], or (FAST) X | U of the NLP iterate
+    constexpr int ITEMS = (FB + REST * 8) / 16;
+    constexpr int NII = ni_of(FB + REST * 8);
+    constexpr int I_LT = FB / 8, I_R = FAST ? I_LT : I_LT + 48;    // doubles (FAST: no residual part -- the operand fetches below stay inside the slot)
     Bundle<NII, ITEMS> bin;
     Bundle<1, AFFINE ? 24 : 39> bout;
     {
-        // (FAST: the first 48 columns of the G1 row -- X | U of the NLP iterate -- ride in the slot of [QLAM, QT]: same bundle shape)
-        const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, FAST ? 0 : O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)};
-        bin.setup(si, lane);
+        if (FAST) { const Seg si[2] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, 0, 18)}; bin.setup(si, lane); }
+        else { const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)}; bin.setup(si, lane); }
         if (AFFINE) { const Seg so[1] = {segd(w.G3, w.ld, O_DLAM, 48)}; bout.setup(so, lane); }
         else { const Seg so[1] = {segd(w.G3, w.ld, O_DW, 78)}; bout.setup(so, lane); }
         bout.seek(0, 1);                                           // (stage k stores row k-1, starting with row 0)
@@ -1310,8 +1321,8 @@ SE_PASS StepInfo forward_pass()
         FT e1 = fac[ex];
         double own_d = dxk[lo12], ov_d = dxk[lov];
         const double *lt = rowp + I_LT, *r = rowp + I_R;
-        double dvl = op[jl], ll = lt[FAST ? jl_val : jl], tl = lt[24 + jl], lu = lt[12 + jl], tu = lt[36 + jl];
-        double rdl = r[jl], rdu = r[12 + jl], rml = r[24 + jl], rmu = r[36 + jl];
+        double dvl = op[jl], ll = lt[FAST ? jl_val : jl], tl = lt[FAST ? 0 : 24 + jl], lu = lt[FAST ? 0 : 12 + jl], tu = lt[FAST ? 0 : 36 + jl];
+        double rdl = r[FAST ? 0 : jl], rdu = r[FAST ? 0 : 12 + jl], rml = r[FAST ? 0 : 24 + jl], rmu = r[FAST ? 0 : 36 + jl];
         if (FAST) rdl = op[12 + (jl < 6 ? jl : jl - 6)];           // (the velocity step of the same joint: NaN check)
 #pragma unroll
         for (int j = 0; j < NX; j++) { asm volatile("" : "+v"(m[j])); pin(x[j]); }
@@ -1525,8 +1536,8 @@ SE_PASS void corrector_pass(double sigma_mu)
 
 // =============================================================================================== fast path: commit
 // The accepted candidate becomes the QP iterate (mpc_core.h fast_commit): (QW | QPI) <- (DW | DPI), QLAM <- 0, QT <- the slacks in DT.
-// Item-parallel, straight from / to the stage records.  The x part of stage 0 keeps the embedded x_hat - x_0 the right-hand-side
-// pass wrote (the sweep's dx_0 is 0); stage 0's y already holds W (r + G [dx0]).
+// Item-parallel, straight from / to the stage records.  The x part of stage 0 is the embedded x_hat - x_0 (the sweep's dx_0 is 0);
+// stage 0's y already holds W (r + G [dx0]) from the right-hand-side pass.
 SE_PASS void fast_commit()
 {
     SSmem &sm = g_ssm;
@@ -1557,7 +1568,10 @@ SE_PASS void fast_commit()
                     const int k = e / IPS, c = 2 * (e - k * IPS);
                     D2 v = stp[r];
                     if (c >= 18 && k >= N) { v.x = 0.0; v.y = 0.0; }             // no multiplier beyond the last dynamics
-                    if (!(k == 0 && c >= 6 && c < 18)) *(MPC_GLOBAL D2 *)(rec(k, c) + O_QW) = v;
+                    if (k == 0 && c >= 6 && c < 18) {                            // x_0 = x_hat (lbx_0 = ubx_0): the sweep's dx_0 is 0
+                        v.x = sm.xhat[c - 6] - *(rec(0, c - 6) + O_X); v.y = sm.xhat[c - 5] - *(rec(0, c - 5) + O_X);
+                    }
+                    *(MPC_GLOBAL D2 *)(rec(k, c) + O_QW) = v;
                 }
             }
         }
@@ -1611,7 +1625,7 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
             tried = 1;
             if (nlp_prev) residual_pass<4>(0.0, nlp_prev); else residual_pass<3>(0.0);
             nlp_prev = nullptr;                                    // the previous step's residuals are done, whatever happens next
-            fact_pass<FT>();
+            fact_pass<FT, true>();
             const double ok = unid(forward_pass<FT, false, true>().alpha);
             if (uni(ok > 0.5 ? 1 : 0)) {
                 fast_commit();

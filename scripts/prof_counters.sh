@@ -13,19 +13,22 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- "$@" > $OUT/sq2.log 2>&1 || echo "sq2 pass failed"
 cd $R
 python3 - "$OUT" <<'PY'
-import csv, glob, os, json, sys
+import csv, glob, os, json, sys, statistics
 out = sys.argv[1]
-summary = {}
+per = {}
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "mpc_" not in k: continue
         kn = k.split("(")[0][:40]
-        summary.setdefault(kn, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-res = {kn: {c: sum(v) / len(v) for c, v in d.items()} for kn, d in summary.items()}
+        d = per.setdefault(kn, {}).setdefault(row["Counter_Name"], {})
+        key = (f, row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        d[key] = d.get(key, 0.0) + float(row["Counter_Value"])      # rows of one dispatch are summed ...
+res = {kn: {c: statistics.median(v.values()) for c, v in d.items()} for kn, d in per.items()}   # ... the per-launch figure is the median over dispatches
 for kn, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0      # wide streaming reads: x2 (MI355X_MICROARCH.md)
+        d["hbm_bytes_per_launch_raw"] = (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
 for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         if "mpc_" in row.get("Name", ""):
