@@ -469,7 +469,7 @@ static void ipm_residuals(int N, const double *H, const double *g, const double 
 /* Backward Riccati factorisation + solve of the Newton system
  *   (H+Gamma) dw + E' dpi = -gt ,  E dw = -rb   (dx_0 = 0)
  * classical recursion on dense 18x18 blocks; factor != 0 refactorises. */
-static int ipm_riccati(int N, const double *A, const double *B, ipm_ws *ws, int factor)
+static int ipm_riccati_fx(int N, const double *A, const double *B, ipm_ws *ws, int factor, const unsigned char *fixed /* [N][6] or NULL */)
 {
     double BA[NX * NW];
     for (int i = 0; i < NX; i++) {
@@ -503,6 +503,9 @@ static int ipm_riccati(int N, const double *A, const double *B, ipm_ws *ws, int 
             for (int j = 0; j < NX; j++) s += BA[j * NW + i] * m[j];
             h[i] = s;
         }
+        /* active-set fast path: a FIXED input (du_j = 0 in this solve) leaves the stage problem -- identity row / column in
+         * R~ = G_uu, zero row in S~ = G_ux, zero entry in h_u -- AFTER the B'PB terms have been added */
+        if (fixed) for (int j = 0; j < NU; j++) if (fixed[(size_t)k * NU + j]) h[j] = 0.0;
         if (factor) {
             double PBA[NX * NW], G[NW * NW];
             for (int i = 0; i < NX; i++)
@@ -517,6 +520,12 @@ static int ipm_riccati(int N, const double *A, const double *B, ipm_ws *ws, int 
                     for (int r = 0; r < NX; r++) s += BA[r * NW + i] * PBA[r * NW + j];
                     G[i * NW + j] = s;
                 }
+            if (fixed)
+                for (int j = 0; j < NU; j++)
+                    if (fixed[(size_t)k * NU + j]) {
+                        for (int c = 0; c < NW; c++) { G[j * NW + c] = 0.0; G[c * NW + j] = 0.0; }
+                        G[j * NW + j] = 1.0;
+                    }
             for (int i = 0; i < NU; i++)
                 for (int j = 0; j < NU; j++) L[i * NU + j] = G[i * NW + j];
             if (chol_lower(L, NU)) return -1;
@@ -591,6 +600,11 @@ static int ipm_riccati(int N, const double *A, const double *B, ipm_ws *ws, int 
         for (int i = 0; i < NX; i++) dwN[NU + i] = dx[i];
     }
     return 0;
+}
+
+static int ipm_riccati(int N, const double *A, const double *B, ipm_ws *ws, int factor)
+{
+    return ipm_riccati_fx(N, A, B, ws, factor, NULL);
 }
 
 /* Build (H+Gamma, gt) from the current residuals (HPIPM compute_Gamma_gamma restated),
@@ -671,57 +685,126 @@ static int ipm_build_mask(int N, const double *lb, const double *ub, unsigned ch
  * t = slack) on acceptance; returns 0 and leaves the warm start (w, pi, lam, t) UNTOUCHED otherwise.
  * Replaces nothing in the reference's results beyond qp_tol: simulator.py:212 sees the same u to ~1e-9. */
 #define ORC_FAST_MARGIN 1e-3
+#define ORC_AS_MAXTRY 3
+/* ACTIVE-SET form of the fast path (fast_path >= 3).  Some inputs ride their bounds (the start-up transient, tight limits): guess the
+ * active set -- the input components whose multiplier exceeded their slack in the previous QP's solution, one stage later (the
+ * horizon recedes by one stage per MPC step) -- FIX them at their bounds (du = bound - u), solve the reduced equality-constrained QP
+ * by the same Riccati sweep (identity rows in R~, zero rows in S~), and accept when every FREE bounded component clears its bounds by
+ * the margin and every FIXED one has a multiplier >= 0: those are the KKT conditions of the inequality-constrained QP, so the point
+ * is its (unique) solution.  Otherwise fix what is violated, release what has a negative multiplier, and solve again, at most
+ * ORC_AS_MAXTRY times; position (q) bounds are never fixed -- one of them violated rejects.  With an empty guess this is the plain
+ * fast path.  `nsolve` returns the number of Riccati factorisations spent. */
+static int ipm_fast_path_as(int N, const double *H, const double *g, const double *b, const double *A, const double *B,
+                            const double *lb, const double *ub, const double *dx0, double *w, double *pi, double *lam,
+                            double *t, ipm_ws *ws, int use_as, int *nsolve)
+{
+    unsigned char *code = (unsigned char *)calloc((size_t)(N + 1) * NU, 1), *fixed = (unsigned char *)calloc((size_t)(N + 1) * NU, 1);
+    double *w0 = (double *)calloc((size_t)(N + 1) * NW, sizeof(double)), *mult = (double *)calloc((size_t)(N + 1) * NU, sizeof(double));
+    int accepted = 0;
+    *nsolve = 0;
+    if (!code || !fixed || !w0 || !mult) goto done;
+    ipm_build_mask(N, lb, ub, ws->mask);
+    if (use_as)
+        for (int k = 0; k < N; k++) {
+            const int ks = k + 1 < N ? k + 1 : k;     /* the previous solution, one stage later */
+            for (int j = 0; j < NU; j++) {
+                const unsigned char *mk = ws->mask + (size_t)k * 24;
+                const double *lk = lam + (size_t)ks * 24, *tk = t + (size_t)ks * 24;
+                code[(size_t)k * NU + j] = (mk[j] && lk[j] > tk[j]) ? 1 : ((mk[12 + j] && lk[12 + j] > tk[12 + j]) ? 2 : 0);
+            }
+        }
+    for (int tr = 0; tr < (use_as ? ORC_AS_MAXTRY : 1); tr++) {
+        /* point the solve starts from: x_0 embedded, fixed inputs on their bounds, everything else 0 */
+        memset(w0, 0, (size_t)(N + 1) * NW * sizeof(double));
+        for (int i = 0; i < NX; i++) w0[NU + i] = dx0[i];
+        for (int k = 0; k < N; k++)
+            for (int j = 0; j < NU; j++) {
+                const unsigned char c = code[(size_t)k * NU + j];
+                fixed[(size_t)k * NU + j] = c != 0;
+                if (c) w0[(size_t)k * NW + j] = c == 1 ? lb[(size_t)k * NB + j] : ub[(size_t)k * NB + j];
+            }
+        for (int k = 0; k <= N; k++) {
+            double *Ht = ws->Ht + (size_t)k * 324, *gt = ws->gt + (size_t)k * NW;
+            memcpy(Ht, H + (size_t)k * 324, 324 * sizeof(double));
+            for (int i = 0; i < NW; i++) {
+                double s = g[(size_t)k * NW + i];
+                for (int c = 0; c < NW; c++) s += Ht[i * NW + c] * w0[(size_t)k * NW + c];
+                gt[i] = s;
+            }
+            if (k == 0) for (int j = 0; j < NX; j++) gt[NU + j] = 0;   /* x_0 is eliminated */
+            if (k == N) for (int j = 0; j < NU; j++) gt[j] = 0;        /* no input at stage N */
+            if (k < N) {
+                double *rbk = ws->rb + (size_t)k * NX;
+                for (int i = 0; i < NX; i++) {
+                    double s = b[(size_t)k * NX + i] - w0[(size_t)(k + 1) * NW + NU + i];
+                    for (int j = 0; j < NX; j++) s += A[i * NX + j] * w0[(size_t)k * NW + NU + j];
+                    for (int j = 0; j < NU; j++) s += B[i * NU + j] * w0[(size_t)k * NW + j];
+                    rbk[i] = s;
+                }
+            }
+        }
+        (*nsolve)++;
+        if (ipm_riccati_fx(N, A, B, ws, 1, fixed)) break;
+        /* candidate = w0 + dw ; verdict per component */
+        int ok = 1, changes = 0, hopeless = 0;
+        for (int k = 0; k <= N && !hopeless; k++) {
+            const unsigned char *mk = ws->mask + (size_t)k * 24;
+            for (int i = 0; i < NW; i++) {
+                const double v = w0[(size_t)k * NW + i] + ws->dw[(size_t)k * NW + i];
+                if (v != v) { hopeless = 1; break; }
+                if (i >= NB) continue;
+                if (i < NU && k < N && code[(size_t)k * NU + i]) {
+                    /* fixed input: its multiplier is the stationarity residual of the candidate in that row */
+                    double r = g[(size_t)k * NW + i];
+                    for (int c = 0; c < NW; c++) r += H[(size_t)k * 324 + i * NW + c] * (w0[(size_t)k * NW + c] + ws->dw[(size_t)k * NW + c]);
+                    for (int c = 0; c < NX; c++) r += B[c * NU + i] * ws->dpi[(size_t)k * NX + c];
+                    const double m_ = code[(size_t)k * NU + i] == 1 ? r : -r;
+                    mult[(size_t)k * NU + i] = m_;
+                    if (!(m_ >= 0.0)) { ok = 0; code[(size_t)k * NU + i] = 0; changes++; }
+                    continue;
+                }
+                const int lo_ok = !mk[i] || v - lb[(size_t)k * NB + i] >= ORC_FAST_MARGIN;
+                const int hi_ok = !mk[12 + i] || ub[(size_t)k * NB + i] - v >= ORC_FAST_MARGIN;
+                if (lo_ok && hi_ok) continue;
+                ok = 0;
+                const int below = mk[i] && v - lb[(size_t)k * NB + i] < 0.0, above = mk[12 + i] && ub[(size_t)k * NB + i] - v < 0.0;
+                if (below || above) {
+                    if (i >= NU || !use_as) { hopeless = 1; break; }       /* a position bound (or no active-set mode): not ours */
+                    code[(size_t)k * NU + i] = below ? 1 : 2; changes++;
+                }   /* inside the margin but feasible: neither accepted nor a reason to fix it */
+            }
+        }
+        if (hopeless) break;
+        if (ok) {
+            for (int k = 0; k <= N; k++) {
+                const unsigned char *mk = ws->mask + (size_t)k * 24;
+                for (int i = 0; i < NW; i++) w[(size_t)k * NW + i] = w0[(size_t)k * NW + i] + ws->dw[(size_t)k * NW + i];
+                if (k < N) memcpy(pi + (size_t)k * NX, ws->dpi + (size_t)k * NX, NX * sizeof(double));
+                for (int j = 0; j < NB; j++) {
+                    const double v = w[(size_t)k * NW + j];
+                    const unsigned char c = (j < NU && k < N) ? code[(size_t)k * NU + j] : 0;
+                    lam[(size_t)k * 24 + j] = c == 1 ? mult[(size_t)k * NU + j] : 0.0;
+                    lam[(size_t)k * 24 + 12 + j] = c == 2 ? mult[(size_t)k * NU + j] : 0.0;
+                    t[(size_t)k * 24 + j] = mk[j] ? (c == 1 ? 0.0 : v - lb[(size_t)k * NB + j]) : 1.0;
+                    t[(size_t)k * 24 + 12 + j] = mk[12 + j] ? (c == 2 ? 0.0 : ub[(size_t)k * NB + j] - v) : 1.0;
+                }
+            }
+            accepted = 1;
+            break;
+        }
+        if (!changes) break;
+    }
+done:
+    free(code); free(fixed); free(w0); free(mult);
+    return accepted;
+}
+
 static int ipm_fast_path(int N, const double *H, const double *g, const double *b, const double *A, const double *B,
                          const double *lb, const double *ub, const double *dx0, double *w, double *pi, double *lam,
                          double *t, ipm_ws *ws)
 {
-    ipm_build_mask(N, lb, ub, ws->mask);
-    for (int k = 0; k <= N; k++) {
-        double *Ht = ws->Ht + (size_t)k * 324, *gt = ws->gt + (size_t)k * NW;
-        memcpy(Ht, H + (size_t)k * 324, 324 * sizeof(double));
-        for (int i = 0; i < NW; i++) {
-            double s = g[(size_t)k * NW + i];
-            if (k == 0) for (int j = 0; j < NX; j++) s += Ht[i * NW + NU + j] * dx0[j];   /* H_0 [0; dx0] */
-            gt[i] = s;
-        }
-        if (k == 0) for (int j = 0; j < NX; j++) gt[NU + j] = 0;   /* x_0 is eliminated */
-        if (k == N) for (int j = 0; j < NU; j++) gt[j] = 0;        /* no input at stage N */
-        if (k < N) {
-            double *rbk = ws->rb + (size_t)k * NX;
-            for (int i = 0; i < NX; i++) {
-                double s = b[(size_t)k * NX + i];
-                if (k == 0) for (int j = 0; j < NX; j++) s += A[i * NX + j] * dx0[j];
-                rbk[i] = s;
-            }
-        }
-    }
-    if (ipm_riccati(N, A, B, ws, 1)) return 0;
-    /* candidate = [0; dx0] + dw ; accept when every bounded component clears its bounds by the margin; a NaN anywhere
-     * rejects (nothing has been written yet: the warm start stays as it was) */
-    for (int k = 0; k <= N; k++) {
-        const unsigned char *mk = ws->mask + (size_t)k * 24;
-        for (int i = 0; i < NW; i++) {
-            double v = ws->dw[(size_t)k * NW + i] + ((k == 0 && i >= NU) ? dx0[i - NU] : 0.0);
-            if (v != v) return 0;
-            if (i < NB) {
-                if (mk[i] && !(v - lb[(size_t)k * NB + i] >= ORC_FAST_MARGIN)) return 0;
-                if (mk[12 + i] && !(ub[(size_t)k * NB + i] - v >= ORC_FAST_MARGIN)) return 0;
-            }
-        }
-    }
-    for (int k = 0; k <= N; k++) {
-        const unsigned char *mk = ws->mask + (size_t)k * 24;
-        for (int i = 0; i < NW; i++)
-            w[(size_t)k * NW + i] = ws->dw[(size_t)k * NW + i] + ((k == 0 && i >= NU) ? dx0[i - NU] : 0.0);
-        if (k < N) memcpy(pi + (size_t)k * NX, ws->dpi + (size_t)k * NX, NX * sizeof(double));
-        for (int j = 0; j < NB; j++) {
-            double v = w[(size_t)k * NW + j];
-            lam[(size_t)k * 24 + j] = 0; lam[(size_t)k * 24 + 12 + j] = 0;
-            t[(size_t)k * 24 + j] = mk[j] ? v - lb[(size_t)k * NB + j] : 1.0;
-            t[(size_t)k * 24 + 12 + j] = mk[12 + j] ? ub[(size_t)k * NB + j] - v : 1.0;
-        }
-    }
-    return 1;
+    int n;
+    return ipm_fast_path_as(N, H, g, b, A, B, lb, ub, dx0, w, pi, lam, t, ws, 0, &n);
 }
 
 /* Mehrotra predictor-corrector IPM; restates HPIPM's d_ocp_qp_ipm_solve main loop
@@ -1035,10 +1118,10 @@ static int solve_qp(orc_solver *s, const double *xhat, int *iters)
     for (int i = 0; i < 12; i++) dx0[i] = xhat[i] - s->x[i];
     if (s->p.fast_path && s->fast_skip > 0 && s->p.fast_path != 2) s->fast_skip--;
     else if (s->p.fast_path) {
-        tried = 1;
-        if (ipm_fast_path(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt, &s->ws)) {
+        if (ipm_fast_path_as(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt, &s->ws,
+                             s->p.fast_path >= 3, &tried)) {
             s->fast_back = 0; s->n_fast++;
-            *iters = 1;
+            *iters = tried;
             return 0;
         }
         s->fast_back = s->fast_back ? (2 * s->fast_back < 8 ? 2 * s->fast_back : 8) : 1;

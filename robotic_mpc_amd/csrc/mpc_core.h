@@ -2923,7 +2923,10 @@ struct Engine {
                     out.sqp_iter[sb + i] = sqp_iter;
                     out.qp_iter[sb + i] = qp_iter;
                     out.cost[sb + i] = cost;
-                    out.solver_time[sb + i] = t1 - t0;
+                    // (SQP_RTI: the plant step and its log ran on a spare lane INSIDE the last NLP pass, i.e. inside [t0, t1]: its time is
+                    // reported as plant_time and taken out here, so that solver_time is the solve alone -- acados time_tot,
+                    // simulator.py:220 -- and the two columns do not count the same microseconds twice)
+                    out.solver_time[sb + i] = (t1 - t0) - (plant_done ? sm.ret[6] : 0.0);
                 }
                 if (lane >= 12 && lane < 16) out.residuals[(sb + i) * 4 + (lane - 12)] =
                     lane == 12 ? res4[0] : (lane == 13 ? res4[1] : (lane == 14 ? res4[2] : res4[3]));

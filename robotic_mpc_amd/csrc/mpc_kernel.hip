@@ -635,7 +635,11 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
             // longer horizons at one simulation per CU run the same sweeps one LDS segment at a time (Engine::segment_ok): eight
             // wavefronts there as well (batch 256, N = 200: 244.8 k vs 234.5 k steps/s; N = 300: 144.5 k vs 137.9 k)
             const bool segments = lay_segment_ok(p->N, h->pool_doubles, 16);
-            if (wpc == 1 && p->N >= 80 && (resident || segments)) nw = 8;
+            // Round 4, with one factorisation per step (the fast path) the item phases are a fifth of a step instead of two fifths, and
+            // the recursion wavefront alone on its SIMD matters more (profiles/r04_geometry.txt, batch 256, 4 / 8 wavefronts, ms per
+            // launch): N = 80 83.8 / 85.9, N = 100 99.9-100.6 / 101.6-102.4, N = 125 90.4 / 88.0 (400 steps), N = 200 116.4 / 115.4,
+            // N = 300 139.0 / 135.1 -- eight from N = 112 on (80 in round 3)
+            if (wpc == 1 && p->N >= 112 && (resident || segments)) nw = 8;
         }
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }
         if (const char *e3 = getenv("MPCB_WPE")) { if (atoi(e3) == 2 && nw == 4) wpe = 2; else if (atoi(e3) == 1) wpe = 1; }
