@@ -693,10 +693,10 @@ static int ipm_build_mask(int N, const double *lb, const double *ub, unsigned ch
  * the margin and every FIXED one has a multiplier >= 0: those are the KKT conditions of the inequality-constrained QP, so the point
  * is its (unique) solution.  Otherwise fix what is violated, release what has a negative multiplier, and solve again, at most
  * ORC_AS_MAXTRY times; position (q) bounds are never fixed -- one of them violated rejects.  With an empty guess this is the plain
- * fast path.  `nsolve` returns the number of Riccati factorisations spent. */
+ * fast path.  `shift`: this is the first QP of an MPC step (later QPs of a full-SQP step keep the stage index: same horizon).  `nsolve` returns the number of Riccati factorisations spent. */
 static int ipm_fast_path_as(int N, const double *H, const double *g, const double *b, const double *A, const double *B,
                             const double *lb, const double *ub, const double *dx0, double *w, double *pi, double *lam,
-                            double *t, ipm_ws *ws, int use_as, int *nsolve)
+                            double *t, ipm_ws *ws, int use_as, int shift, int *nsolve)
 {
     unsigned char *code = (unsigned char *)calloc((size_t)(N + 1) * NU, 1), *fixed = (unsigned char *)calloc((size_t)(N + 1) * NU, 1);
     double *w0 = (double *)calloc((size_t)(N + 1) * NW, sizeof(double)), *mult = (double *)calloc((size_t)(N + 1) * NU, sizeof(double));
@@ -706,7 +706,7 @@ static int ipm_fast_path_as(int N, const double *H, const double *g, const doubl
     ipm_build_mask(N, lb, ub, ws->mask);
     if (use_as)
         for (int k = 0; k < N; k++) {
-            const int ks = k + 1 < N ? k + 1 : k;     /* the previous solution, one stage later */
+            const int ks = (shift && k + 1 < N) ? k + 1 : k;     /* the previous solution, one stage later at the first QP of an MPC step */
             for (int j = 0; j < NU; j++) {
                 const unsigned char *mk = ws->mask + (size_t)k * 24;
                 const double *lk = lam + (size_t)ks * 24, *tk = t + (size_t)ks * 24;
@@ -804,7 +804,7 @@ static int ipm_fast_path(int N, const double *H, const double *g, const double *
                          double *t, ipm_ws *ws)
 {
     int n;
-    return ipm_fast_path_as(N, H, g, b, A, B, lb, ub, dx0, w, pi, lam, t, ws, 0, &n);
+    return ipm_fast_path_as(N, H, g, b, A, B, lb, ub, dx0, w, pi, lam, t, ws, 0, 0, &n);
 }
 
 /* Mehrotra predictor-corrector IPM; restates HPIPM's d_ocp_qp_ipm_solve main loop
@@ -1111,7 +1111,7 @@ static void nlp_residuals(const orc_solver *s, const double *xhat, double *res4)
  * The fast path is attempted at every QP, except that a REJECTED attempt (some bound within the margin: the factorisation
  * was wasted) suspends the attempts for the next 1, 2, 4, 8, 8, ... QPs of this solver (doubling while the rejections go on,
  * back to none after an acceptance), so that a simulation riding its bounds pays at most one wasted factorisation in nine. */
-static int solve_qp(orc_solver *s, const double *xhat, int *iters)
+static int solve_qp(orc_solver *s, const double *xhat, int *iters, int first_qp)
 {
     double dx0[12];
     int tried = 0, it = 0;
@@ -1119,7 +1119,7 @@ static int solve_qp(orc_solver *s, const double *xhat, int *iters)
     if (s->p.fast_path && s->fast_skip > 0 && s->p.fast_path != 2) s->fast_skip--;
     else if (s->p.fast_path) {
         if (ipm_fast_path_as(s->N, s->H, s->g, s->b, s->A, s->B, s->lb, s->ub, dx0, s->qw, s->qpi, s->qlam, s->qt, &s->ws,
-                             s->p.fast_path >= 3, &tried)) {
+                             s->p.fast_path >= 3, first_qp, &tried)) {
             s->fast_back = 0; s->n_fast++;
             *iters = tried;
             return 0;
@@ -1233,7 +1233,7 @@ int orc_solver_step(orc_solver *s, const double *xhat, double *u0, int *sqp_iter
     if (s->p.solver_type == 1) {
         /* SQP_RTI: one linearisation, one QP, full step (acados ocp_nlp_sqp_rti) */
         linearize(s);
-        int qs = solve_qp(s, xhat, &it);
+        int qs = solve_qp(s, xhat, &it, 1);
         qp_iter += it;
         sqp_iter = 1;
         if (qs != 0 && qs != 1) status = 4; /* ACADOS_QP_FAILURE; iterate left untouched */
@@ -1253,7 +1253,7 @@ int orc_solver_step(orc_solver *s, const double *xhat, double *u0, int *sqp_iter
                 if (res[0] < s->p.tol && res[1] < te && res[2] < ti && res[3] < tc) { status = 0; break; }
             }
             if (res[0] != res[0] || s->cost != s->cost) { status = 1; break; }
-            int qs = solve_qp(s, xhat, &it);
+            int qs = solve_qp(s, xhat, &it, sqp_iter == 0);
             qp_iter += it;
             if (qs != 0 && qs != 1) { status = 4; break; }
             double alpha = line_search(s, xhat, sqp_iter);

@@ -61,7 +61,8 @@ typedef struct {
     double lm;
     /* bound-inactive fast path of the QP solve (an addition of this build, see ipm_fast_path in mpc_oracle.c):
      * 0 off (every QP through the interior-point loop, as HPIPM), 1 on (attempted by the rule in solve_qp),
-     * 2 attempted at every QP (diagnostic) */
+     * 2 attempted at every QP (diagnostic), 3 the active-set form (diagnostic: exists in the oracle only -- measured on the
+     * engines and not adopted) */
     int fast_path;
 } orc_params;
 
