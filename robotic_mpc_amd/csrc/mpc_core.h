@@ -433,6 +433,7 @@ struct Engine {
         // LDS: the linearisation records of as many stages as fit (row stride L2N: lane <-> stage accesses without bank aliasing)
         const int CH = ex.uni(imax(1, imin(ex.smem().pool_n / L2N, NS)));
         double *const v2 = ex.pool();
+        PROF_T0(tu);
         if (do_update) {
             // (X | U) += alpha * (dx | du): G1 columns [0, 18) <- columns [24, 36) | [18, 24); SQP: multipliers blend towards the QP's
             constexpr int IPS = 9, R = rounds_for(IPS);
@@ -488,10 +489,12 @@ struct Engine {
             }
             ex.barrier();
         }
+        PROF_ADD(PF_X1, tu);
         double cost = 0.0, rs = 0.0, re = 0.0, ri = 0.0, rc = 0.0;
         for (int k0 = 0; k0 <= Nl; k0 += CH) {
             const int k1 = imin(k0 + CH - 1, Nl);
             // ---- linearise: lane <-> stage
+            PROF_T0(tl);
             ex.par([&](int lane) {
                 double csum = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
@@ -546,6 +549,8 @@ struct Engine {
                 ex.put_sum(sm.red[4], lane, csum);
             });
             cost += ex.get_sum(sm.red[4]);
+            PROF_ADD(PF_X2, tl);
+            PROF_T0(tn);
             // ---- residual norms: joint items (k, j < 6): rows u_j, q_j, v_j of the stationarity residual, their bounds, the defect
             if (res4) {
                 constexpr int R = rounds_for(6);
@@ -640,6 +645,7 @@ struct Engine {
                 constexpr int NL = decltype(nl)::value;
                 copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
             });
+            PROF_ADD(PF_X3, tn);
         }
         if (res4) { res4[0] = rs; res4[1] = re; res4[2] = ri; res4[3] = rc; }
         PROF_ADD(PF_NLP, t0);

@@ -25,7 +25,7 @@ for i in range(B):
 pb, bufs = eng.run_device(cf, ch)
 ms = sum(eng.last_kernel_ms)
 print(f"B={B} N={N} Nsim={pb.Nsim}: kernel {ms:.1f} ms -> {B*pb.Nsim/(ms*1e-3):.0f} steps/s, per step {ms/pb.Nsim*1e3:.1f} us")
-names = ["nlp", "res", "fact", "bwd", "fwd", "merit", "plant", "total", "ipm_iters", "io", "seq_fact", "seq_bwd", "seq_fwd", "res_A", "res_B", "res_C"]
+names = ["nlp", "res", "fact", "bwd", "fwd", "merit", "plant", "total", "ipm_iters", "io", "seq_fact", "seq_bwd", "seq_fwd", "res_A|nlp_update", "res_B|nlp_linearise", "res_C|nlp_norms+store"]
 out = (C.c_double * 16)()
 eng.lib.mpcb_debug_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
 for inst in (0, B // 2):

@@ -134,7 +134,14 @@ def test_asm_scanner_detects_empty_exec_reload():
     # second check: register spills in the item-parallel passes (a scratch reload drains every prefetch in flight)
     hot = "_ZN4mpcb6EngineI7DevExecILi8ELi1EEE12fwd_residentILb0ELb0EEEdv"
     spilled = "\n".join([hot + ":"] + ["\tscratch_load_dword v1, off, s32"] * 12 + [".Lfunc_end0:", "_Z5otherv:", "\tscratch_load_dword v1, off, s32"])
-    assert mod.scratch_ops(spilled) == {hot: 12}
+    assert mod.scratch_ops(spilled) == {hot: (12, mod.MAX_SCRATCH_OPS)}           # name -> (count, limit)
+    # round 4: the two-per-CU build and the throughput engine's sweeps are guarded too; functions with a recorded budget pass below it
+    for name in ("_ZN4mpcb6EngineI7DevExecILi4ELi2EEE15residual_directEid", "_ZN4mpcb2se9fact_passIdLb0EEEvv"):
+        txt = "\n".join([name + ":"] + ["\tscratch_load_dword v1, off, s32"] * 9 + [".Lfunc_end0:"])
+        assert mod.scratch_ops(txt) == {name: (9, mod.MAX_SCRATCH_OPS)}, name
+    nlp = "_ZN4mpcb6EngineI7DevExecILi8ELi1EEE10nlp_directEdbbPdb"
+    assert mod.scratch_ops("\n".join([nlp + ":"] + ["\tscratch_load_dword v1, off, s32"] * 100 + [".Lfunc_end0:"])) == {}
+    assert nlp in mod.scratch_ops("\n".join([nlp + ":"] + ["\tscratch_load_dword v1, off, s32"] * 200 + [".Lfunc_end0:"]))
 
 
 def test_generated_isa_has_no_vector_op_under_empty_exec():
