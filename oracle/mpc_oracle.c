@@ -1219,7 +1219,9 @@ static double line_search(orc_solver *s, const double *xhat, int sqp_iter)
             if (k < N)
                 for (int i = 0; i < 6; i++) s->tu[(size_t)k * 6 + i] = s->u[(size_t)k * 6 + i] + alpha * s->qw[(size_t)k * 18 + i];
         }
-        if (merit_fun(s, s->tx, s->tu, xhat) < m0) break;
+        const double m1 = merit_fun(s, s->tx, s->tu, xhat);
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "line search sqp %d alpha %.4f: merit %.17g vs %.17g (%+.3e)\n", sqp_iter, alpha, m1, m0, m1 - m0);
+        if (m1 < m0) break;
         alpha *= 0.7;
     }
     return alpha;
