@@ -47,8 +47,15 @@ constexpr int L1 = 98;
 // same reason for the part [R..GV] (60 doubles) of the G2 record that the NLP pass builds with one
 // lane per stage (every lane touches the same column of a different stage): stride 62
 constexpr int L2N = 62;
+// the whole G2 record (112 doubles: the linearisation AND the fast path's right-hand side, written by the same NLP pass): stride 114
+// (912 B = 3 x 256 + 9 x 16: sixteen consecutive stages fall on sixteen different 16-byte bank groups)
+constexpr int L2W = 114;
 
 #define NLP_PASS nlp_direct
+// 1 (default): SQP_RTI folds the fast path's commit and right-hand-side item passes into the NLP pass; 0: separate passes (A/B builds)
+#ifndef MPCB_FUSE
+#define MPCB_FUSE 1
+#endif
 #ifdef MPCB_PROFILE
 #define PROF_T0(v) const double v = ex.clock()
 #define PROF_ADD(i, v) prof[i] += ex.clock() - v
@@ -138,11 +145,15 @@ struct Engine {
     int N;
     double lin_cost;  // cost of the linearisation currently held in G2
     int fast_skip, fast_back;   // fast path: QPs left before the next attempt; length of the current suspension (ipm::fast_backoff)
+    // SQP_RTI, fast path: the two item passes around the sweeps are folded into the NLP pass that follows / precedes them
+    //   commit_pending  the accepted candidate has not been written to the QP iterate yet: the next NLP pass does it with its update
+    //   rhs_valid       G2 already holds the fast path's right-hand side (gt, Gamma = 0, rb) for the current linearisation and x_hat
+    bool commit_pending, rhs_valid;
 #ifdef MPCB_PROFILE
     double prof[NPROF];
 #endif
 
-    MPC_HD Engine(Ex &e, const Ctx &cc) : ex(e), c(cc), N(cc.N), lin_cost(0.0), fast_skip(0), fast_back(0)
+    MPC_HD Engine(Ex &e, const Ctx &cc) : ex(e), c(cc), N(cc.N), lin_cost(0.0), fast_skip(0), fast_back(0), commit_pending(false), rhs_valid(false)
     {
         ex.par([&](int lane) {
             if (lane == 0) { Smem &sm = ex.smem(); sm.w = cc.w; sm.n_hor = cc.N; sm.pool_n = cc.pool_n; }
@@ -383,6 +394,29 @@ struct Engine {
     MPC_HD static double gld(const double *p) { return *(MPC_GLOBAL const double *)p; }
     MPC_HD static void gst(double *p, double v) { *(MPC_GLOBAL double *)p = v; }
 
+    // The fast path's right-hand side of joint j at one stage (Gamma = 0): condensed gradient gt = g at (dw, pi, lam) = 0 with the
+    // feedback step dx_0 = x_hat - x_0 embedded, and rb = b + A dx_0.  ONE function with explicit fused multiply-adds for its two
+    // callers -- fast_rhs (a pass of its own: first attempt of a launch, SQP) and the residual-norm items of nlp_direct (SQP_RTI) -- so
+    // that a run cut into several launches reproduces the single launch bit for bit whichever of them formed the right-hand side.
+    struct RhsItem { double gtu, gtq, gtv, rbq, rbv; };
+    MPC_HD static RhsItem rhs_item(const InstParams &P, int j, bool st, bool inner, double uj, double vj, double dxq, double dxv,
+                                   double g0, double g1, double g2, double g3, double g4, double y0, double y1, double y2, double y3,
+                                   double y4, double gv, double bdq, double bdv)
+    {
+        const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+        const double vjn = vj + dxv;
+        double s_ = g0 * y0;
+        s_ = fma(g1, y1, s_); s_ = fma(g2, y2, s_); s_ = fma(g3, y3, s_); s_ = fma(g4, y4, s_);
+        const double tu = fma(c2, uj - vjn, 2.0 * P.w_u * uj), tv = fma(c2, vjn - uj, gv * y4);
+        RhsItem o;
+        o.gtu = st ? P.dt * tu : 0.0;
+        o.gtq = st && inner ? P.dt * s_ : 0.0;
+        o.gtv = st && inner ? P.dt * tv : 0.0;
+        o.rbq = st ? fma(P.a12[j], dxv, dxq) + bdq : 0.0;
+        o.rbv = st ? fma(P.a22[j], dxv, bdv) : 0.0;
+        return o;
+    }
+
     // =========================================================================== NLP pass
     // One pass over the horizon that (optionally) applies the SQP/RTI step to the iterate
     // (acados ocp_nlp_update_variables_sqp), linearises at the new iterate -- task residual and
@@ -422,7 +456,14 @@ struct Engine {
     // `do_plant` (SQP_RTI: this is the last pass of solve()): the plant step with u = solver.get(0,'u') and the FK / J qdot / task-error
     // log of the NEW plant state (simulation_model.py:85-91) are one lane's work; they run here on a lane that has no stage to
     // linearise, in the shadow of the linearisation, instead of alone after the solve (6 us per MPC step).  Results in sm.logv / sm.u0.
-    MPC_PASS double nlp_direct(double alpha, bool do_update, bool sqp_mult, double *res4, bool do_plant = false)
+    // `fuse_commit` (SQP_RTI, the fast path accepted its candidate and left it in the Newton-step slots): fast_commit's work is done by
+    // the update items here -- the candidate becomes the QP iterate AND is added to (X | U) by the same item, one pass and one read of the
+    // step less.  `want_rhs` (SQP_RTI, the next QP will try the fast path): the joint items of the residual norms also form the fast
+    // path's right-hand side for the NEW plant state (gt = g, Gamma = 0, rb = b + A dx_0: the same products the stationarity rows are
+    // made of), so fast_rhs needs no pass of its own; with room for whole G2 records in LDS (stride L2W) it leaves with the
+    // linearisation in one coalesced store, otherwise by 8-byte stores from the items.
+    MPC_PASS double nlp_direct(double alpha, bool do_update, bool sqp_mult, double *res4, bool do_plant = false, bool fuse_commit = false,
+                               bool want_rhs = false)
     {
         PROF_T0(t0);
         Smem &sm = ex.smem();
@@ -430,11 +471,75 @@ struct Engine {
         const Robot &rb = sm.rb;
         const int Nl = ex.uni(ex.smem().n_hor), NS = Nl + 1;
         double *const G1 = ex.smem().w.G1, *const G5 = ex.smem().w.G5;
+        want_rhs = ex.uni(want_rhs && res4 != nullptr && do_plant);
+        const bool wide = ex.uni(want_rhs && ex.smem().pool_n >= NS * L2W);   // the whole horizon's G2 records fit: one chunk
+        const int LS = wide ? L2W : L2N;
         // LDS: the linearisation records of as many stages as fit (row stride L2N: lane <-> stage accesses without bank aliasing)
-        const int CH = ex.uni(imax(1, imin(ex.smem().pool_n / L2N, NS)));
+        const int CH = ex.uni(imax(1, imin(ex.smem().pool_n / LS, NS)));
         double *const v2 = ex.pool();
         PROF_T0(tu);
-        if (do_update) {
+        if (ex.uni(do_update && fuse_commit)) {
+            // fast_commit + update in one: item (k, c) of the 15 pairs of (QW | QPI) <- (DW | DPI) [x_0 embedded, the multiplier shifted by
+            // one stage]; the 9 pairs of QW are also the step of (X | U).  Then QLAM <- 0, QT <- the candidate's slacks.
+            double *const G3 = ex.smem().w.G3;
+            {
+                constexpr int IPS = 15, R = rounds_for(IPS);
+                const int items = NS * IPS;
+                for (int base = 0; base < items; base += R * NT) {
+                    ex.wpar([&](int lane) {
+                        D2 cur[R], stp[R];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
+                            stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)(c >= 18 ? imin(k + 1, Nl) : k) * W3 + O_DW + c);
+                            cur[r] = *(MPC_GLOBAL const D2 *)(G1 + (size_t)k * W1 + (c < 6 ? 12 + c : (c < 18 ? c - 6 : 0)));
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = base + r * NT + lane;
+                            if (e < items) {
+                                const int k = e / IPS, c = 2 * (e - k * IPS);
+                                D2 v = stp[r];
+                                if (c >= 18 && k >= Nl) { v.x = 0.0; v.y = 0.0; }              // no multiplier beyond the last dynamics
+                                if (c < 18) {
+                                    D2 x = cur[r];
+                                    if (k == 0 && c >= 6) { v.x = sm.xhat[c - 6] - x.x; v.y = sm.xhat[c - 5] - x.y; }   // x_0 = x_hat (lbx_0 = ubx_0)
+                                    const double aa = (c < 6 && k >= Nl) ? 0.0 : alpha;   // no input at stage N
+                                    x.x += aa * v.x; x.y += aa * v.y;
+                                    *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + (c < 6 ? 12 + c : c - 6)) = x;
+                                }
+                                *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QW + c) = v;
+                            }
+                        }
+                    });
+                }
+            }
+            {
+                constexpr int IPS = 24, R = rounds_for(IPS);
+                const int items = NS * IPS;
+                for (int base = 0; base < items; base += R * NT) {
+                    ex.wpar([&](int lane) {
+                        D2 stp[R];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = imin(base + r * NT + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
+                            stp[r] = *(MPC_GLOBAL const D2 *)(G3 + (size_t)k * W3 + O_DT + (q >= 24 ? q - 24 : 0));
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int e = base + r * NT + lane;
+                            if (e < items) {
+                                const int k = e / IPS, q = 2 * (e - k * IPS);
+                                D2 v = stp[r];
+                                if (q < 24) { v.x = 0.0; v.y = 0.0; }
+                                *(MPC_GLOBAL D2 *)(G1 + (size_t)k * W1 + O_QLAM + q) = v;
+                            }
+                        }
+                    });
+                }
+            }
+            ex.barrier();
+        } else if (do_update) {
             // (X | U) += alpha * (dx | du): G1 columns [0, 18) <- columns [24, 36) | [18, 24); SQP: multipliers blend towards the QP's
             constexpr int IPS = 9, R = rounds_for(IPS);
             const int items = NS * IPS;
@@ -498,7 +603,7 @@ struct Engine {
             ex.par([&](int lane) {
                 double csum = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
-                    double *rec = v2 + (size_t)(k - k0) * L2N;
+                    double *rec = v2 + (size_t)(k - k0) * LS;
                     if (k < Nl) {
                         const double *g1 = G1 + (size_t)k * W1;
                         double xx[12], uu[6], xn[12];
@@ -577,7 +682,7 @@ struct Engine {
                             const int e = base + r * NT + lane;
                             if (e < items) {
                                 const int s = e / 6, j = e - s * 6, k = k0 + s;
-                                const double *rec = v2 + (size_t)s * L2N;
+                                double *rec = v2 + (size_t)s * LS;
                                 const double uj = v[r][0], qj = v[r][1], vj = v[r][2];
                                 const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
                                 double as_ = a_s.at(lane), ai_ = a_i.at(lane), ac_ = a_c.at(lane);
@@ -628,6 +733,26 @@ struct Engine {
                                 if (k < Nl) a_e.at(lane) = fmax(a_e.at(lane), fmax(fabs(rec[O_BD + j]), fabs(rec[O_BD + 6 + j])));
                                 if (k == 0) ai_ = fmax(ai_, fmax(fabs(sm.xhat[j] - qj), fabs(sm.xhat[6 + j] - vj)));   // lbx_0 = ubx_0 = x_hat
                                 a_s.at(lane) = as_; a_i.at(lane) = ai_; a_c.at(lane) = ac_;
+                                if (want_rhs) {
+                                    // the fast path's right-hand side of the NEXT QP (fast_rhs): the new plant state is in sm.logv[24..35]
+                                    // (the plant lane of the linearisation phase above)
+                                    const double dxq = k == 0 ? sm.logv[24 + j] - qj : 0.0, dxv = k == 0 ? sm.logv[30 + j] - vj : 0.0;
+                                    const RhsItem o = rhs_item(P, j, k < Nl, k >= 1, uj, vj, dxq, dxv, rec[O_GQ + j], rec[O_GQ + 6 + j],
+                                                               rec[O_GQ + 12 + j], rec[O_GQ + 18 + j], rec[O_GQ + 24 + j], rec[O_Y], rec[O_Y + 1],
+                                                               rec[O_Y + 2], rec[O_Y + 3], rec[O_Y + 4], rec[O_GV + j], rec[O_BD + j],
+                                                               rec[O_BD + 6 + j]);
+                                    if (wide) {
+                                        rec[O_GT + j] = o.gtu; rec[O_GT + 6 + j] = o.gtq; rec[O_GT + 12 + j] = o.gtv;
+                                        rec[O_GAM + j] = 0.0; rec[O_GAM + 6 + j] = 0.0;
+                                        rec[O_RB + j] = o.rbq; rec[O_RB + 6 + j] = o.rbv;
+                                        if (j < 2) rec[10 + j] = 0.0;     // (the record's two unused columns leave with it)
+                                    } else {
+                                        double *g2 = ex.smem().w.G2 + (size_t)k * W2;
+                                        gst(g2 + O_GT + j, o.gtu); gst(g2 + O_GT + 6 + j, o.gtq); gst(g2 + O_GT + 12 + j, o.gtv);
+                                        gst(g2 + O_GAM + j, 0.0); gst(g2 + O_GAM + 6 + j, 0.0);
+                                        gst(g2 + O_RB + j, o.rbq); gst(g2 + O_RB + 6 + j, o.rbv);
+                                    }
+                                }
                             }
                         }
                     });
@@ -643,7 +768,8 @@ struct Engine {
             }
             copies([&](int lane, auto nl) {
                 constexpr int NL = decltype(nl)::value;
-                copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
+                if (wide) copy_lanes<W2, 0, W2, L2W, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
+                else copy_lanes<W2_LIN, 0, W2, L2N, false, NL>(v2, ex.smem().w.G2, k0, k1, lane);
             });
             PROF_ADD(PF_X3, tn);
         }
@@ -2443,7 +2569,6 @@ struct Engine {
         double *const G1 = ex.smem().w.G1, *const G2 = ex.smem().w.G2;
         constexpr int R = rounds_for(6);
         const int items = NS * 6;
-        const double dt = P.dt;
         for (int base = 0; base < items; base += R * NT) {
             ex.wpar([&](int lane) {
                 double v[R][16];
@@ -2462,22 +2587,13 @@ struct Engine {
                     const int e = base + r * NT + lane;
                     if (e < items) {
                         const int k = e / 6, j = e - k * 6;
-                        const bool st = k < Nl;
                         const double dxq = k == 0 ? sm.xhat[j] - v[r][2] : 0.0, dxv = k == 0 ? sm.xhat[6 + j] - v[r][1] : 0.0;
-                        const double uj = v[r][0], vj = v[r][1] + dxv;
-                        const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
-                        double s_ = 0.0;
-#pragma unroll
-                        for (int i = 0; i < NTASK; i++) s_ += v[r][4 + i] * v[r][9 + i];
-                        const double gtu = st ? dt * (2.0 * P.w_u * uj + c2 * (uj - vj)) : 0.0;
-                        const double gtq = st && k >= 1 ? dt * s_ : 0.0;
-                        const double gtv = st && k >= 1 ? dt * (v[r][3] * v[r][13] + c2 * (vj - uj)) : 0.0;
-                        const double rbq = st ? (dxq + P.a12[j] * dxv) + v[r][14] : 0.0;
-                        const double rbv = st ? P.a22[j] * dxv + v[r][15] : 0.0;
+                        const RhsItem o = rhs_item(P, j, k < Nl, k >= 1, v[r][0], v[r][1], dxq, dxv, v[r][4], v[r][5], v[r][6], v[r][7], v[r][8],
+                                                   v[r][9], v[r][10], v[r][11], v[r][12], v[r][13], v[r][3], v[r][14], v[r][15]);
                         double *g2 = G2 + (size_t)k * W2;
-                        gst(g2 + O_GT + j, gtu); gst(g2 + O_GT + 6 + j, gtq); gst(g2 + O_GT + 12 + j, gtv);
+                        gst(g2 + O_GT + j, o.gtu); gst(g2 + O_GT + 6 + j, o.gtq); gst(g2 + O_GT + 12 + j, o.gtv);
                         gst(g2 + O_GAM + j, 0.0); gst(g2 + O_GAM + 6 + j, 0.0);
-                        gst(g2 + O_RB + j, rbq); gst(g2 + O_RB + 6 + j, rbv);
+                        gst(g2 + O_RB + j, o.rbq); gst(g2 + O_RB + 6 + j, o.rbv);
                     }
                 }
             });
@@ -2566,7 +2682,9 @@ struct Engine {
     // =========================================================================== IPM driver
     // Restates HPIPM's d_ocp_qp_ipm_solve main loop (see oracle/mpc_oracle.c ipm_solve).
     // Returns HPIPM status 0 ok / 1 max-iter / 2 min-step / 3 NaN.
-    MPC_HD int ipm_solve(int *iters_out)
+    // `defer_commit` (SQP_RTI): an accepted fast-path candidate is left in the Newton-step slots with commit_pending set; the NLP pass
+    // that follows writes it to the QP iterate together with its own update (nlp_direct fuse_commit).
+    MPC_HD int ipm_solve(int *iters_out, bool defer_commit = false)
     {
         const double tol = ex.smem().P.qp_tol;
         Smem &sm = ex.smem();
@@ -2582,14 +2700,16 @@ struct Engine {
             if (fast_skip > 0) fast_skip--;
             else {
                 tried = 1;
-                fast_rhs();
+                if (!rhs_valid) fast_rhs();   // (SQP_RTI: normally formed by the previous step's NLP pass, nlp_direct want_rhs)
+                rhs_valid = false;
                 double ok;
                 if (res) { fact_pass_t<1>(); ok = fwd_resident<false, false, false, true>(); }
                 else if (reg) { fact_pass_t<2>(); ok = fwd_resident<false, true, true, true>(); }
                 else if (seg) { fact_pass_t<2>(); ok = fwd_resident<false, true, false, true>(); }
                 else { fact_pass_t<0>(); ok = forward_step_pass<false, true>(); }
                 if (ex.uni(ok > 0.5)) {
-                    fast_commit();
+                    if (defer_commit) commit_pending = true;
+                    else fast_commit();
                     fast_back = 0;
 #ifdef MPCB_PROFILE
                     prof[PF_COUNT_IPM] += 1;
@@ -2601,6 +2721,7 @@ struct Engine {
                 fast_skip = fast_back;
             }
         }
+        rhs_valid = false;            // (the interior-point passes rebuild Gamma, gt, rb)
         residual_direct(0, 0.0);
         const double nc = ex.uni(sm.ret[5]);
         double mu = nc > 0 ? ex.uni(sm.ret[4]) / nc : 0.0;
@@ -2831,15 +2952,20 @@ struct Engine {
         double cost = lin_cost;
         if (c.pb->solver_type == 1) {
             // SQP_RTI: one linearisation, one QP, full step
-            if (!lin_valid) cost = NLP_PASS(0.0, false, false, nullptr);
-            const int qs = ipm_solve(&it);
+            if (!lin_valid) { cost = NLP_PASS(0.0, false, false, nullptr); rhs_valid = false; }
+            commit_pending = false;
+            const int qs = ipm_solve(&it, MPCB_FUSE != 0);
             qp_iter += it;
             sqp_iter = 1;
             const bool ok = qs == 0 || qs == 1;
             if (!ok) status = 4;  // ACADOS_QP_FAILURE, iterate untouched
             // residuals / cost are evaluated at the new iterate (acados get_residuals() for RTI,
-            // get_cost()); this linearisation is reused by the next solve() call
-            cost = NLP_PASS(1.0, ok, false, res4, true);
+            // get_cost()); this linearisation is reused by the next solve() call -- and so is the fast path's right-hand side,
+            // formed by the same pass when the next QP will try the fast path (ipm_solve: fast_off == 0 and no suspension left)
+            const bool next_fast = ex.uni(MPCB_FUSE != 0 && ex.smem().P.fast_off == 0.0 && fast_skip == 0);
+            cost = NLP_PASS(1.0, ok, false, res4, true, commit_pending, next_fast);
+            rhs_valid = next_fast;
+            commit_pending = false;
             *plant_done = true;
             lin_valid = true;
         } else {
@@ -2903,6 +3029,7 @@ struct Engine {
             });
             lin_cost = w.state[12];
             lin_valid = ex.uni(w.state[25] != 0.0);
+            rhs_valid = false;     // (not carried across launches: the first fast attempt of a launch forms its right-hand side itself)
             fast_skip = ex.uni((int)w.state[26]); fast_back = ex.uni((int)w.state[27]);
         }
         for (int i = step0; i < step1; i++) {
