@@ -1007,6 +1007,175 @@ SE_PASS IpmNorms residual_items(double a)
     return r;
 }
 
+// SQP_RTI, the first pass of a step, ITEM-parallel (round 4): what residual_pass<3 | 4> and nlp_res_pass<false> did stage by stage with
+// 10-20 lanes busy per role (~400 instructions per stage: 154 us of a 586 us fast-path step at batch 4096) has no recursion in it -- every
+// element is a function of its own stage's records and one row of each neighbour -- so the 64 lanes take 64 JOINT ITEMS (k, j < 6) at a
+// time, operands straight from the stage records into registers (residual_items above; mpc_core.h nlp_direct's joint items):
+//   NORMS  acados get_residuals / get_cost of the iterate lin_pass has just linearised (nlp_res_pass<false>): dynamics defect BD -> G2,
+//          cost = sum_k dt/2 r'Wr, inf-norms [stat, eq, ineq, comp] with the QP's multipliers as the last solve left them;
+//          out5 = [cost, stat, eq, ineq, comp]; `xsel`: x_hat that solve was made for (0: sm.xhat, 1: sm.vec[3])
+//   RHS    right-hand side of the bound-inactive fast path for the NEW x_hat (residual_pass<3>; mpc_core.h fast_rhs): Gamma = 0,
+//          gt = g at (dw, pi, lam) = 0 with dx_0 = x_hat - x_0 embedded, rb = b + A dx_0; stage 0's y = W (r + G dx_0)
+// ONE function for every place the norms are formed (fused with the right-hand side, alone at the end of a launch / work item, before
+// an interior-point solve), so a run cut into work items reproduces the plain launch bit for bit.
+template <bool NORMS, bool RHS>
+SE_PASS void rti_items(int xsel, double *out5)
+{
+    SSmem &sm = g_ssm;
+    const InstParams &P = sm.P;
+    const int lane = threadIdx.x;
+    const int N = uni(sm.n_hor), NS = N + 1;
+    const SWs w = sm.w;
+    const int LD = uni(w.ld >> 3);
+    MPC_GLOBAL char *const gb = (MPC_GLOBAL char *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)w.G1 >> 32)) << 32) |
+                                                    (unsigned)uni((int)(unsigned long long)w.G1));
+    auto rec = [&](int k, int col) { return (MPC_GLOBAL double *)(gb + (unsigned)((k * LD + col) << 3)); };
+    constexpr int C2 = W1;
+    auto gld = [](const MPC_GLOBAL double *p) { return *p; };
+    auto gst = [](MPC_GLOBAL double *p, double v) { *p = v; };
+    // stage 0's joint items are lanes 0..5 of the first batch: their x_hat entries wait in registers (an LDS read inside the item loop
+    // would make the compiler drain the loads in flight)
+    const int l6 = lane < 6 ? lane : 0;
+    const double xh_q = sm.xhat[l6], xh_v = sm.xhat[6 + l6];
+    const double xp_q = xsel ? sm.vec[3][l6] : xh_q, xp_v = xsel ? sm.vec[3][6 + l6] : xh_v;
+    wait_vm<0>();
+    fence();
+    double csum = 0.0, n_s = 0, n_e = 0, n_i = 0, n_c = 0;
+    constexpr int R = 2;
+    const int items = NS * 6;
+    const double dt = P.dt;
+    for (int base = 0; base < items; base += R * WAVE) {
+        double x[R][3], m[R][14], g[R][12], bd[R][2];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = imin(base + r * WAVE + lane, items - 1), k = e / 6, j = e - k * 6, km = imax(k - 1, 0), kn = imin(k + 1, N);
+            const MPC_GLOBAL double *g1 = rec(k, j), *g2 = g1 + C2, *y = rec(k, 0) + C2 + O_Y;
+            x[r][0] = gld(g1 + O_U); x[r][1] = gld(g1 + O_X); x[r][2] = gld(g1 + O_X + 6);
+            g[r][0] = gld(g2 + O_GV);
+#pragma unroll
+            for (int i = 0; i < NTASK; i++) { g[r][1 + i] = gld(g2 + O_GQ + i * 6); g[r][6 + i] = gld(y + i); }
+            if (NORMS) {
+                const MPC_GLOBAL double *gm = rec(km, j), *gn = rec(kn, j);
+                m[r][0] = gld(g1 + O_QPI); m[r][1] = gld(g1 + O_QPI + 6); m[r][2] = gld(gm + O_QPI); m[r][3] = gld(gm + O_QPI + 6);
+                m[r][4] = gld(g1 + O_QLAM);     m[r][5] = gld(g1 + O_QLAM + 12); m[r][6] = gld(g1 + O_QT);     m[r][7] = gld(g1 + O_QT + 12);    // u_j
+                m[r][8] = gld(g1 + O_QLAM + 6); m[r][9] = gld(g1 + O_QLAM + 18); m[r][10] = gld(g1 + O_QT + 6); m[r][11] = gld(g1 + O_QT + 18);  // q_j
+                m[r][12] = gld(gn + O_X); m[r][13] = gld(gn + O_X + 6);
+                g[r][11] = gld(rec(k, j < NTASK ? j : 0) + C2 + O_R);
+            } else {
+                bd[r][0] = gld(g2 + O_BD); bd[r][1] = gld(g2 + O_BD + 6);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = base + r * WAVE + lane;
+            if (e < items) {
+                const int k = e / 6, j = e - k * 6;
+                const double uj = x[r][0], qj = x[r][1], vj = x[r][2];
+                const double c2 = P.w_qddot * P.cq[j] * P.cq[j];
+                const bool st = k < N;
+                double s_ = 0.0;
+#pragma unroll
+                for (int i = 0; i < NTASK; i++) s_ += g[r][1 + i] * g[r][6 + i];
+                double bdq, bdv;
+                MPC_GLOBAL double *g2 = rec(k, j) + C2;
+                if (NORMS) {
+                    // dynamics defect (prediction_model.py:317-320) and this joint's share of the cost
+                    bdq = 0.0; bdv = 0.0;
+                    if (st) {
+                        bdq = (qj + P.a12[j] * vj + P.b1[j] * uj) - m[r][12];
+                        bdv = (P.a22[j] * vj + P.b2[j] * uj) - m[r][13];
+                        n_e = fmax(n_e, fmax(fabs(bdq), fabs(bdv)));
+                        const double qdd = P.cq[j] * (uj - vj);
+                        csum += 0.5 * dt * (2.0 * P.w_u * uj * uj + P.w_qddot * qdd * qdd);
+                        if (j < NTASK) csum += 0.5 * dt * P.w_task[j] * g[r][11] * g[r][11];
+                    }
+                    gst(g2 + O_BD, bdq); gst(g2 + O_BD + 6, bdv);
+                    // stationarity of the NLP at the iterate, rows u_j, q_j, v_j (mpc_core.h stat_cls without delta), bounds, complementarity
+                    auto bound = [&](int ci, bool hc, double cur, double l_lo, double l_hi, double t_lo, double t_hi, double &val) {
+                        if (hc) {
+                            if (bnd_lo(P, ci) > -BOUND_INF) {
+                                val -= l_lo;
+                                n_i = fmax(n_i, fabs((bnd_lo(P, ci) - cur) + t_lo));
+                                n_c = fmax(n_c, fabs(l_lo * t_lo));
+                            }
+                            if (bnd_hi(P, ci) < BOUND_INF) {
+                                val += l_hi;
+                                n_i = fmax(n_i, fabs((cur - bnd_hi(P, ci)) + t_hi));
+                                n_c = fmax(n_c, fabs(l_hi * t_hi));
+                            }
+                        }
+                    };
+                    double ru = 0.0;
+                    if (st) {
+                        ru = dt * (2.0 * P.w_u * uj + c2 * (uj - vj));
+                        ru += P.b1[j] * m[r][0] + P.b2[j] * m[r][1];
+                    }
+                    bound(j, st, uj, m[r][4], m[r][5], m[r][6], m[r][7], ru);
+                    double rq = 0.0;
+                    if (k > 0) {
+                        if (st) rq = dt * s_ + m[r][0];
+                        rq -= m[r][2];
+                    }
+                    bound(6 + j, k >= 1 && st, qj, m[r][8], m[r][9], m[r][10], m[r][11], rq);
+                    double rv = 0.0;
+                    if (k > 0) {
+                        if (st) {
+                            rv = dt * (g[r][0] * g[r][10] + c2 * (vj - uj));
+                            rv += P.a12[j] * m[r][0] + P.a22[j] * m[r][1];
+                        }
+                        rv -= m[r][3];
+                    }
+                    if (k == 0) {
+                        rq = 0.0; rv = 0.0;                                               // x_0 is eliminated (lbx_0 = ubx_0)
+                        n_i = fmax(n_i, fmax(fabs(xp_q - qj), fabs(xp_v - vj)));          // ... = x_hat of that QP
+                    }
+                    n_s = fmax(n_s, fmax(fabs(ru), fmax(fabs(rq), fabs(rv))));
+                } else {
+                    bdq = bd[r][0]; bdv = bd[r][1];
+                }
+                if (RHS) {
+                    const double dxq = k == 0 ? xh_q - qj : 0.0, dxv = k == 0 ? xh_v - vj : 0.0;
+                    const double vjn = vj + dxv;
+                    const double gtu = st ? dt * (2.0 * P.w_u * uj + c2 * (uj - vjn)) : 0.0;
+                    const double gtq = st && k >= 1 ? dt * s_ : 0.0;
+                    const double gtv = st && k >= 1 ? dt * (g[r][0] * g[r][10] + c2 * (vjn - uj)) : 0.0;
+                    const double rbq = st ? (dxq + P.a12[j] * dxv) + bdq : 0.0;
+                    const double rbv = st ? P.a22[j] * dxv + bdv : 0.0;
+                    gst(g2 + O_GT, gtu); gst(g2 + O_GT + 6, gtq); gst(g2 + O_GT + 12, gtv);
+                    gst(g2 + O_GAM, 0.0); gst(g2 + O_GAM + 6, 0.0);
+                    gst(g2 + O_RB, rbq); gst(g2 + O_RB + 6, rbv);
+                }
+            }
+        }
+    }
+    if (RHS) {
+        // stage 0's y with the feedback step embedded (residual_pass lanes 48..52; read by the SQP merit weights): lane i < 5
+        const int i = lane < NTASK ? lane : 0;
+        const MPC_GLOBAL double *r0 = rec(0, 0);
+        double v = gld(r0 + C2 + O_R + i), gq[6], gv[6], xq[6], xv[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { gq[j] = gld(r0 + C2 + O_GQ + i * 6 + j); gv[j] = gld(r0 + C2 + O_GV + j); xq[j] = gld(r0 + O_X + j); xv[j] = gld(r0 + O_X + 6 + j); }
+        double dq[6], dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { dq[j] = lane_val(xh_q, j) - xq[j]; dv[j] = lane_val(xh_v, j) - xv[j]; }
+        if (N > 0) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) v += gq[j] * dq[j];
+            if (i == 4) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) v += gv[j] * dv[j];
+            }
+            if (lane < NTASK) gst(rec(0, i) + C2 + O_Y, P.w_task[i] * v);
+        }
+    }
+    if (NORMS && out5) {
+        out5[0] = wsum(csum);
+        out5[1] = wmax(n_s); out5[2] = wmax(n_e); out5[3] = wmax(n_i); out5[4] = wmax(n_c);
+    }
+    wait_vm<0>();
+    fence();
+}
+
 // =============================================================================================== factorisation sweep
 // Backward Riccati sweep, matrix AND vector recursion of a stage in the same two phases (mpc_core.h fact_pass):
 //   lanes 0..35  block (a,b) of the 12x12 cost-to-go in registers for the whole sweep
@@ -1623,12 +1792,27 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
         if (fast[0] > 0) fast[0]--;
         else {
             tried = 1;
+            SPROF_T0(t_r);
+#ifdef MPCB_STREAM_SEQ_RES
             if (nlp_prev) residual_pass<4>(0.0, nlp_prev); else residual_pass<3>(0.0);
+#else
+            if (nlp_prev) rti_items<true, true>(1, nlp_prev); else rti_items<false, true>(0, nullptr);
+#endif
+            SPROF_ADD(10, t_r);
             nlp_prev = nullptr;                                    // the previous step's residuals are done, whatever happens next
+            SPROF_T0(t_f);
             fact_pass<FT, true>();
+            SPROF_ADD(11, t_f);
+            SPROF_T0(t_w);
             const double ok = unid(forward_pass<FT, false, true>().alpha);
+            SPROF_ADD(12, t_w);
             if (uni(ok > 0.5 ? 1 : 0)) {
+                SPROF_T0(t_c);
                 fast_commit();
+                SPROF_ADD(13, t_c);
+#ifdef MPCB_SPROF
+                if (threadIdx.x == 0) g_ssm.w.state[32 + 15] += 1.0;
+#endif
                 fast[1] = 0;
                 *iters_out = 1;
                 return 0;
@@ -1638,7 +1822,12 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
         }
     }
     // nlp_prev: the NLP residual / cost of the previous step's iterate is still to be evaluated -- by this QP's first pass
+#ifdef MPCB_STREAM_SEQ_RES
     IpmNorms r = nlp_prev ? residual_pass<2>(0.0, nlp_prev) : residual_pass<0>(0.0);
+#else
+    if (nlp_prev) rti_items<true, false>(1, nlp_prev);     // (the same items as everywhere else: see rti_items)
+    IpmNorms r = residual_pass<0>(0.0);
+#endif
     const double nc = unid(r.nc);
     double mu = nc > 0 ? unid(r.smu) / nc : 0.0;
     int it = 0, status = 1;
@@ -2069,7 +2258,16 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         const double t0 = wclock();
         if (pb.solver_type == 1) {
             // SQP_RTI: one linearisation, one QP, full step (mpc_core.h nlp_step)
+#ifdef MPCB_STREAM_SEQ_RES
             if (!lin_valid) { lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence(); lin_cost = unid(nlp_res_pass<false>(nullptr)); }
+#else
+            if (!lin_valid) {
+                lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence();
+                double o5[5];
+                rti_items<true, false>(0, o5);
+                lin_cost = unid(o5[0]);
+            }
+#endif
             double nlp_prev[5];
             const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, fast, res_pending ? nlp_prev : nullptr);
             if (res_pending) {
@@ -2096,7 +2294,13 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
                 res_pending = true;
                 if (lane < NX) sm.vec[3][lane] = sm.xhat[lane];        // the x_hat this QP was solved for
             } else {
+#ifdef MPCB_STREAM_SEQ_RES
                 cost = unid(nlp_res_pass<false>(res4));                // last step of this launch / work item
+#else
+                double o5[5];
+                rti_items<true, false>(0, o5);                         // last step of this launch / work item
+                cost = unid(o5[0]); res4[0] = o5[1]; res4[1] = o5[2]; res4[2] = o5[3]; res4[3] = o5[4];
+#endif
             }
             SPROF_ADD(9, tn);
             lin_valid = true;
@@ -2190,6 +2394,9 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         log_lo = uni(log_state(out, inst, T1, i + 1, log_lo));
         const double t2 = wclock();
         if (lane == 0) out.plant_time[sbase + i] = t2 - t1;
+#ifdef MPCB_SPROF
+        if (lane == 0) { w.state[32 + 14] += t2 - t1; }
+#endif
     }
     if (log_lo <= step1) log_flush(out, inst, T1, log_lo, step1);
     if (lane < NX) w.state[lane] = sm.xhat[lane];
