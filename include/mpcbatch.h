@@ -63,12 +63,13 @@ extern "C" {
  * items: same results bit for bit, balanced launch (MPCB_STREAM_CHUNK=0 turns it off; a hand-off that does not complete
  * within a bound derived from the work limit of one chunk -- 4 x chunk steps x SQP iterations x QP iterations x (N+1) x 20 us
  * + 30 s; MPCB_QUEUE_TIMEOUT_S overrides it -- is reported by mpcb_sync as MPCB_EHIP instead of hanging). */
-/* Measured crossovers, N=100, 600 steps, one MI355X, fast path of the QP solve on (profiles/r04_engine_sweep.txt; latency engine two
- * simulations per CU vs throughput engine, steps/s).  SQP_RTI: 1536 simulations 2.50 M vs 2.19 M, 2048: 2.59 M vs 2.75 M, 4096: 2.67 M vs
- * 3.18 M.  Full SQP: 2560 simulations 460 k vs 414 k, 4096: 508 k vs 520 k. */
-#define MPCB_STREAM_MIN_BATCH_SQP 3328   /* full SQP: from this many simulations on ... */
+/* Measured crossovers, N=100, 600 steps, one MI355X, fast path of the QP solve on, the throughput engine's first pass of a step
+ * item-parallel (profiles/r04_engine_sweep2.txt; latency engine two simulations per CU vs throughput engine, steps/s).  SQP_RTI: 1024
+ * simulations 2.40 M vs 2.10 M, 1280: 2.34 M vs 2.55 M, 2048: 2.55 M vs 3.69 M, 4096: 2.67 M vs 4.08 M.  Full SQP: 2048 simulations
+ * 474 k vs 435 k, 2560: 447 k vs 489 k, 4096: 503 k vs 601 k (4096 x 100 steps: 131 k vs 145 k). */
+#define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on ... */
 #define MPCB_STREAM_MIN_STEPS_SQP 300    /* ... for runs of at least this many closed-loop steps */
-#define MPCB_STREAM_MIN_BATCH 1920
+#define MPCB_STREAM_MIN_BATCH 1280
 
 typedef struct mpcb_handle mpcb_handle;
 

@@ -1018,7 +1018,8 @@ SE_PASS IpmNorms residual_items(double a)
 //          gt = g at (dw, pi, lam) = 0 with dx_0 = x_hat - x_0 embedded, rb = b + A dx_0; stage 0's y = W (r + G dx_0)
 // ONE function for every place the norms are formed (fused with the right-hand side, alone at the end of a launch / work item, before
 // an interior-point solve), so a run cut into work items reproduces the plain launch bit for bit.
-template <bool NORMS, bool RHS>
+// SQPM (full SQP): the norms use the blended NLP multipliers of G5 (NPI | NLAM | NT: the same relative layout as QPI | QLAM | QT of G1).
+template <bool NORMS, bool RHS, bool SQPM = false>
 SE_PASS void rti_items(int xsel, double *out5)
 {
     SSmem &sm = g_ssm;
@@ -1031,6 +1032,7 @@ SE_PASS void rti_items(int xsel, double *out5)
                                                     (unsigned)uni((int)(unsigned long long)w.G1));
     auto rec = [&](int k, int col) { return (MPC_GLOBAL double *)(gb + (unsigned)((k * LD + col) << 3)); };
     constexpr int C2 = W1;
+    const int CM = SQPM ? uni((int)(w.G5 - w.G1)) + O_NPI : O_QPI;     // column of the multipliers [pi 12 | lam 24 | t 24] in the stage record
     auto gld = [](const MPC_GLOBAL double *p) { return *p; };
     auto gst = [](MPC_GLOBAL double *p, double v) { *p = v; };
     // stage 0's joint items are lanes 0..5 of the first batch: their x_hat entries wait in registers (an LDS read inside the item loop
@@ -1055,10 +1057,10 @@ SE_PASS void rti_items(int xsel, double *out5)
 #pragma unroll
             for (int i = 0; i < NTASK; i++) { g[r][1 + i] = gld(g2 + O_GQ + i * 6); g[r][6 + i] = gld(y + i); }
             if (NORMS) {
-                const MPC_GLOBAL double *gm = rec(km, j), *gn = rec(kn, j);
-                m[r][0] = gld(g1 + O_QPI); m[r][1] = gld(g1 + O_QPI + 6); m[r][2] = gld(gm + O_QPI); m[r][3] = gld(gm + O_QPI + 6);
-                m[r][4] = gld(g1 + O_QLAM);     m[r][5] = gld(g1 + O_QLAM + 12); m[r][6] = gld(g1 + O_QT);     m[r][7] = gld(g1 + O_QT + 12);    // u_j
-                m[r][8] = gld(g1 + O_QLAM + 6); m[r][9] = gld(g1 + O_QLAM + 18); m[r][10] = gld(g1 + O_QT + 6); m[r][11] = gld(g1 + O_QT + 18);  // q_j
+                const MPC_GLOBAL double *gn = rec(kn, j), *mk = rec(k, j + CM), *mm = rec(km, j + CM);
+                m[r][0] = gld(mk); m[r][1] = gld(mk + 6); m[r][2] = gld(mm); m[r][3] = gld(mm + 6);
+                m[r][4] = gld(mk + 12); m[r][5] = gld(mk + 24); m[r][6] = gld(mk + 36);  m[r][7] = gld(mk + 48);    // u_j: lam lo, hi, t lo, hi
+                m[r][8] = gld(mk + 18); m[r][9] = gld(mk + 30); m[r][10] = gld(mk + 42); m[r][11] = gld(mk + 54);   // q_j
                 m[r][12] = gld(gn + O_X); m[r][13] = gld(gn + O_X + 6);
                 g[r][11] = gld(rec(k, j < NTASK ? j : 0) + C2 + O_R);
             } else {
@@ -2317,8 +2319,14 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
                     lin_pass(alpha, pending, true);
                     __builtin_amdgcn_s_waitcnt(0);
                     fence();
+#ifdef MPCB_STREAM_SEQ_RES
                     cost = unid(nlp_res_pass<true>(res4));
                     res4[0] = unid(res4[0]); res4[1] = unid(res4[1]); res4[2] = unid(res4[2]); res4[3] = unid(res4[3]);
+#else
+                    double o5[5];
+                    rti_items<true, false, true>(0, o5);
+                    cost = unid(o5[0]); res4[0] = unid(o5[1]); res4[1] = unid(o5[2]); res4[2] = unid(o5[3]); res4[3] = unid(o5[4]);
+#endif
                     pending = false;
                     lin_valid = true;
                 }
@@ -2338,7 +2346,13 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
                 lin_pass(alpha, true, true);
                 __builtin_amdgcn_s_waitcnt(0);
                 fence();
+#ifdef MPCB_STREAM_SEQ_RES
                 cost = unid(nlp_res_pass<true>(nullptr));
+#else
+                double o5[5];
+                rti_items<true, false, true>(0, o5);
+                cost = unid(o5[0]);
+#endif
                 lin_valid = true;
             }
         }

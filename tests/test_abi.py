@@ -44,18 +44,18 @@ def test_version_and_sizes(lib):
 
 def test_engine_selection_thresholds(lib, monkeypatch):
     """mpcb_engine_for (host logic, no device): which kernel family a uniform bucket goes to, at both sides of every measured
-    crossover of include/mpcbatch.h (profiles/r04_engine_sweep.txt), and the MPCB_ENGINE override."""
+    crossover of include/mpcbatch.h (profiles/r04_engine_sweep2.txt), and the MPCB_ENGINE override."""
     from robotic_mpc_amd import engine
 
     monkeypatch.delenv("MPCB_ENGINE", raising=False)
     hdr = open(os.path.join(ROOT, "include", "mpcbatch.h")).read()
     rti, sqp, steps = (int(re.search(r"#define %s\s+(\d+)" % n, hdr).group(1))
                        for n in ("MPCB_STREAM_MIN_BATCH", "MPCB_STREAM_MIN_BATCH_SQP", "MPCB_STREAM_MIN_STEPS_SQP"))
-    assert (rti, sqp, steps) == (1920, 3328, 300)
+    assert (rti, sqp, steps) == (1280, 2560, 300)
     for batch, N, nsim, solver, prec, want in (
             (256, 100, 600, "SQP_RTI", 0, 0), (rti - 1, 100, 600, "SQP_RTI", 0, 0), (rti, 100, 600, "SQP_RTI", 0, 1),
             (4096, 100, 600, "SQP_RTI", 0, 1), (64, 300, 150, "SQP_RTI", 1, 1),          # fp32 Riccati: throughput engine only
-            (2560, 100, 600, "SQP", 0, 0), (sqp - 1, 100, 600, "SQP", 0, 0), (sqp, 100, 600, "SQP", 0, 1),
+            (2048, 100, 600, "SQP", 0, 0), (sqp - 1, 100, 600, "SQP", 0, 0), (sqp, 100, 600, "SQP", 0, 1),
             (4096, 100, steps - 1, "SQP", 0, 0), (4096, 100, steps, "SQP", 0, 1)):
         assert engine.engine_for(batch, N, nsim, solver, prec, lib=lib) == want, (batch, N, nsim, solver, prec)
     monkeypatch.setenv("MPCB_ENGINE", "stream")

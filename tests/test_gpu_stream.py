@@ -121,8 +121,8 @@ def test_large_rti_batch_takes_the_stream_engine_and_matches_both(orc, ur10, ur1
     cfgs = _jitter(2048, seed=9, prediction_horizon=20, simulation_time=0.3)
     e = engine.MpcBatchEngine(0)
     try:
-        e.setup(cfgs[:1919], ur10)
-        assert e.launch_info()["engine"] == 0                    # below MPCB_STREAM_MIN_BATCH (1920): latency engine
+        e.setup(cfgs[:1279], ur10)
+        assert e.launch_info()["engine"] == 0                    # below MPCB_STREAM_MIN_BATCH (1280): latency engine
         out = e.run(cfgs, ur10)
         assert e.launch_info()["engine"] == 1
         assert (out["status"] == 0).all() and np.isfinite(out["z"]).all()
