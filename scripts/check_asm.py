@@ -43,7 +43,7 @@ def scan(asm_text):
 # so that growth there is a decision, not an accident.  Who owns the kernels' scratch bytes (BENCH roofline.scratch_bytes): these.
 HOT = ("fwd_resident", "corr_resident", "residual_direct", "fact_pass_t", "fast_rhs", "fast_commit", "forward_step_pass", "corrector_bwd_pass")
 HOT_GEOM = ("DevExecILi8ELi1E", "DevExecILi4ELi1E", "DevExecILi4ELi2E")
-HOT_STREAM = ("se9fact_pass", "se12forward_pass", "se14corrector_pass", "se13residual_pass", "se14residual_items", "se11fast_commit", "se12nlp_res_pass")
+HOT_STREAM = ("se9fact_pass", "se12forward_pass", "se14corrector_pass", "se13residual_pass", "se14residual_items", "se11fast_commit", "se12nlp_res_pass", "se9rti_items")
 MAX_SCRATCH_OPS = 8      # (callee-saved registers at a pass's entry / exit)
 # function-name fragment -> scratch operations allowed (the count at the commit that recorded it, + ~10 %)
 BUDGET = {
