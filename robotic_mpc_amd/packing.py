@@ -46,10 +46,11 @@ def pack_batch(cfgs: Sequence[Dict]) -> np.ndarray:
 
 
 # SQP_RTI buckets that differ only in the prediction horizon are merged into one RAGGED launch of the throughput engine once together
-# they reach this many simulations per rank.  Re-derived in round 4 with the fast path of the QP solve in both engines
-# (profiles/r04_config2_shares.txt, BASELINE configs[2] per-GPU shares, one launch / one launch per horizon, run phase): 512 simulations
-# 0.465 / 0.201 s, 1024: 0.480 / 0.325 s, 2048: 0.595 / 0.451 s, 4096: 0.775 / 0.869 s -- the merge pays from ~3000 simulations on.
-RAGGED_MIN_BATCH = 3072
+# they reach this many simulations per rank.  Re-derived at the end of round 4 with the fast path of the QP solve in both engines and the
+# throughput engine's item-parallel first pass (profiles/r04_config2_shares.txt, BASELINE configs[2] per-GPU shares, one launch / one
+# launch per horizon, run phase): 512 simulations 0.309 / 0.199 s, 1024: 0.322 / 0.318 s, 2048: 0.418 / 0.464 s, 4096: 0.603 / 0.848 s --
+# the merge pays from ~1500 simulations on (3072 before the item-parallel pass, 1280 in round 3).
+RAGGED_MIN_BATCH = 2048
 SOLVER_RTI = 1
 
 
