@@ -112,3 +112,33 @@ def test_emulated_plant_integrators(orc, ur10, ur10_rb, method):
     np.testing.assert_allclose(out["z"][0], ref["z"], atol=1e-11, rtol=0)
     rk4 = orc.run(ur10_rb, orc.make_params(_cfg(prediction_horizon=8, simulation_time=0.1)))
     assert np.abs(rk4["z"] - ref["z"]).max() > 1e-6   # the option does change the closed loop
+
+
+def test_emulated_folded_passes_equal_separate_passes(ur10, tmp_path):
+    """Round 4: SQP_RTI folds the fast path's commit and right-hand-side item passes into the NLP pass (mpc_core.h nlp_direct
+    fuse_commit / want_rhs, build switch MPCB_FUSE).  The folded build must reproduce the build with separate passes BIT FOR BIT --
+    one rhs_item function serves both places a right-hand side is formed, the commit's arithmetic is the same additions -- on a run with
+    accepted, rejected and suspended fast-path attempts (tight input bounds at the start), in one launch and cut into launches, with
+    the whole pool (G2 records leave LDS in one store) and with a small one (8-byte stores from the items)."""
+    import subprocess
+
+    import emu
+
+    cfgs = [_cfg(prediction_horizon=30, simulation_time=0.4, qdot_max=np.full(6, 0.6), qdot_min=-np.full(6, 0.6),
+                 q_0=np.array([0.9, -1.2, 1.1, 0.2, 0.4, 0.1])),
+            _cfg(prediction_horizon=30, simulation_time=0.4)]
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import emu, pickle; "
+            "cfgs, chain, kw, dst = pickle.load(open(sys.argv[1], 'rb')); o = emu.run(cfgs, chain, **kw); np.savez(dst, **o)"
+            % (os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import pickle
+
+    for kw in (dict(waves=4), dict(waves=4, step_chunk=7), dict(waves=4, pool_doubles=2048)):
+        out = emu.run(cfgs, ur10, **kw)
+        assert (out["qp_iter"] == 1).any() and (out["qp_iter"] > 1).any()       # both branches of the QP solve were taken
+        job, dst = str(tmp_path / "job.pkl"), str(tmp_path / "sep.npz")
+        pickle.dump((cfgs, ur10, kw, dst), open(job, "wb"))
+        env = dict(os.environ, MPC_EMU_DEFINES="-DMPCB_FUSE=0")
+        subprocess.check_call([sys.executable, "-c", code, job], env=env)
+        sep = np.load(dst)
+        for k in ("z", "u", "ee_pose", "ee_vel", "errors", "cost", "residuals", "status", "sqp_iter", "qp_iter"):
+            np.testing.assert_array_equal(out[k], sep[k], err_msg=f"{kw} {k}")
