@@ -1898,6 +1898,9 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
     const SWs w = sm.w;
     for (int k0 = 0; k0 <= N; k0 += WAVE) {
         const int k = k0 + lane;
+#ifdef MPCB_SPROF_LIN
+        const double tl0 = wclock();
+#endif
         if (k > N) continue;
         MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)k * w.ld);
         MPC_GLOBAL double *r2 = (MPC_GLOBAL double *)((char *)w.G2 + (size_t)k * w.ld);
@@ -1918,6 +1921,11 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
                 for (int i = 0; i < 60; i++) r5[i] += alpha * (r1[O_QPI + i] - r5[i]);   // NPI | NLAM | NT <- QPI | QLAM | QT
             }
         }
+#ifdef MPCB_SPROF_LIN
+        __builtin_amdgcn_s_waitcnt(0);
+        const double tl1 = wclock();
+        if (lane == 0) { g_ssm.w.state[32 + 0] += tl1 - tl0; }
+#endif
         if (k < N) {
             double rl[10];                                             // r | Y; the Jacobian goes straight to the record
             task_lin<true>(rb, P, xx, xx + 6, rl, (double *)r2);
@@ -1931,6 +1939,12 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
 #pragma unroll
             for (int i = O_GQ; i < W2_LIN; i++) r2[i] = 0.0;
         }
+#ifdef MPCB_SPROF_LIN
+        const double tl2 = wclock();
+        __builtin_amdgcn_s_waitcnt(0);
+        const double tl3 = wclock();
+        if (lane == 0) { g_ssm.w.state[32 + 1] += tl2 - tl1; g_ssm.w.state[32 + 2] += tl3 - tl2; }
+#endif
     }
 }
 
