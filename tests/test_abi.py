@@ -51,7 +51,7 @@ def test_engine_selection_thresholds(lib, monkeypatch):
     hdr = open(os.path.join(ROOT, "include", "mpcbatch.h")).read()
     rti, sqp, steps = (int(re.search(r"#define %s\s+(\d+)" % n, hdr).group(1))
                        for n in ("MPCB_STREAM_MIN_BATCH", "MPCB_STREAM_MIN_BATCH_SQP", "MPCB_STREAM_MIN_STEPS_SQP"))
-    assert (rti, sqp, steps) == (1280, 2560, 300)
+    assert (rti, sqp, steps) == (1280, 2560, 200)
     for batch, N, nsim, solver, prec, want in (
             (256, 100, 600, "SQP_RTI", 0, 0), (rti - 1, 100, 600, "SQP_RTI", 0, 0), (rti, 100, 600, "SQP_RTI", 0, 1),
             (4096, 100, 600, "SQP_RTI", 0, 1), (64, 300, 150, "SQP_RTI", 1, 1),          # fp32 Riccati: throughput engine only
