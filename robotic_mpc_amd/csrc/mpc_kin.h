@@ -44,11 +44,40 @@ MPC_HD M3 load_m3(const double *p)
     A.r0 = v3(p[0], p[1], p[2]); A.r1 = v3(p[3], p[4], p[5]); A.r2 = v3(p[6], p[7], p[8]);
     return A;
 }
+// sin and cos of a joint angle.  The library sincos carries a large-argument path (Payne-Hanek, v_trig_preop_f64) that a joint angle never
+// takes but that is compiled into every one of the six calls of a linearisation (~90 instructions each, and its temporaries are where the
+// 256-register builds spill).  Here: Cody-Waite reduction by pi/2 in two fused steps (exact products, k = nearest integer) and the two
+// minimax kernels of fdlibm (k_sin.c / k_cos.c, public domain; < 1 ulp on [-pi/4, pi/4]) -- ~35 instructions, branch-free, absolute error
+// <= 2e-16 for |th| <= 1e6 rad (tests/test_oracle.py checks it against libm on a grid; beyond that the reduction loses bits gradually).
+MPC_HD void sincos_joint(double th, double *sn, double *cs)
+{
+    const double kf = rint(th * 6.36619772367581382433e-01);          // 2/pi
+    double r = fma(-kf, 1.57079632679489655800e+00, th);                // pi/2, rounded
+    r = fma(-kf, 6.12323399573676603587e-17, r);                        // pi/2 - the above
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06); ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03); ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s0 = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07); pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03); pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c0 = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)kf & 3;                                          // quadrant
+    const double sv = (q & 1) ? c0 : s0, cv = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -sv : sv;
+    *cs = ((q + 1) & 2) ? -cv : cv;
+}
+
 // Rodrigues rotation about a unit axis
 MPC_HD M3 axis_rot(V3 a, double th)
 {
     double s, c;
+#ifdef MPCB_LIBM_SINCOS      // (A/B builds)
     sincos(th, &s, &c);
+#else
+    sincos_joint(th, &s, &c);
+#endif
     const double v = 1.0 - c;
     M3 R;
     R.r0 = v3(c + v * a.x * a.x, v * a.x * a.y - s * a.z, v * a.x * a.z + s * a.y);

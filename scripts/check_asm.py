@@ -47,12 +47,14 @@ HOT_STREAM = ("se9fact_pass", "se12forward_pass", "se14corrector_pass", "se13res
 MAX_SCRATCH_OPS = 8      # (callee-saved registers at a pass's entry / exit)
 # function-name fragment -> scratch operations allowed (the count at the commit that recorded it, + ~10 %)
 BUDGET = {
-    # (nlp_direct with the fast path's commit and right-hand side folded in, MPCB_FUSE: 121 / 147 -- measured faster than the leaner separate passes)
-    "DevExecILi8ELi1EEE10nlp_direct": 133, "DevExecILi4ELi2EEE10nlp_direct": 160, "DevExecILi4ELi1EEE10nlp_direct": 8,
-    "DevExecILi8ELi1EEE9log_state": 48, "DevExecILi4ELi2EEE9log_state": 48, "DevExecILi4ELi1EEE9log_state": 8,
-    "10merit_pass": 440, "se8lin_pass": 60, "se9log_state": 40,
-    "18mpc_rollout_kernelILi8ELi1E": 325, "18mpc_rollout_kernelILi4ELi2E": 335, "18mpc_rollout_kernelILi4ELi1E": 240,
-    "17mpc_stream_kernelId": 215, "17mpc_stream_kernelIf": 195,
+    # (round 4, end: the joint-angle sincos of mpc_kin.h replaced the library's, whose large-argument path was what these functions spilled
+    # around: nlp_direct 121 / 147 -> 41 / 54, log_state 43 -> 2, merit_pass 394 -> 186, the throughput engine's lin_pass 56 -> 0 and
+    # log_state 33 -> 0 -- those two are held to the hot passes' limit now)
+    "DevExecILi8ELi1EEE10nlp_direct": 46, "DevExecILi4ELi2EEE10nlp_direct": 60, "DevExecILi4ELi1EEE10nlp_direct": 8,
+    "DevExecILi8ELi1EEE9log_state": 8, "DevExecILi4ELi2EEE9log_state": 8, "DevExecILi4ELi1EEE9log_state": 8,
+    "10merit_pass": 210, "se8lin_pass": 8, "se9log_state": 8,
+    "18mpc_rollout_kernelILi8ELi1E": 340, "18mpc_rollout_kernelILi4ELi2E": 330, "18mpc_rollout_kernelILi4ELi1E": 258,
+    "17mpc_stream_kernelId": 150, "17mpc_stream_kernelIf": 150,
 }
 
 

@@ -146,3 +146,9 @@ extern "C" int emu_run(const Problem *pb, const double *robot105, const double *
     if (waves == 2) return emu_run_t<2>(pb, robot105, params, out, step_chunk, pool_doubles);
     return emu_run_t<1>(pb, robot105, params, out, step_chunk, pool_doubles);
 }
+
+// the product's joint-angle sincos (mpc_kin.h), for tests/test_emulation.py::test_joint_sincos_against_libm
+extern "C" void emu_sincos(int n, const double *th, double *sn, double *cs)
+{
+    for (int i = 0; i < n; i++) sincos_joint(th[i], sn + i, cs + i);
+}
