@@ -638,8 +638,11 @@ int mpcb_setup(mpcb_handle *h, const mpcb_problem *p, const double *params_host,
             // Round 4, with one factorisation per step (the fast path) the item phases are a fifth of a step instead of two fifths, and
             // the recursion wavefront alone on its SIMD matters more (profiles/r04_geometry.txt, batch 256, 4 / 8 wavefronts, ms per
             // launch): N = 80 83.8 / 85.9, N = 100 99.9-100.6 / 101.6-102.4, N = 125 90.4 / 88.0 (400 steps), N = 200 116.4 / 115.4,
-            // N = 300 139.0 / 135.1 -- eight from N = 112 on (80 in round 3)
-            if (wpc == 1 && p->N >= 112 && (resident || segments)) nw = 8;
+            // N = 300 139.0 / 135.1 -- eight from N = 112 on (80 in round 3).  End of round 4: those 256-register builds had been paying for
+            // scratch spills around the library sincos in the NLP pass; with the joint-angle sincos of mpc_kin.h (no spills) eight win
+            // from N = 80 again (profiles/r04_geometry2.txt: N = 50 58.7 / 59.7 ms, N = 80 84.4 / 83.7, N = 100 97.5 / 95.3,
+            // N = 112 111.3 / 106.6)
+            if (wpc == 1 && p->N >= 80 && (resident || segments)) nw = 8;
         }
         if (env && (atoi(env) == 1 || atoi(env) == 2 || atoi(env) == 4 || atoi(env) == 8)) { nw = atoi(env); wpe = 1; }
         if (const char *e3 = getenv("MPCB_WPE")) { if (atoi(e3) == 2 && nw == 4) wpe = 2; else if (atoi(e3) == 1) wpe = 1; }
