@@ -603,6 +603,9 @@ struct Engine {
             ex.par([&](int lane) {
                 double csum = 0.0;
                 for (int k = k0 + lane; k <= k1; k += NT) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MPCB_NO_LICM_BLOCK)
+                    asm volatile("" ::: "memory");     // (parameters are read where they are used, not hoisted out of the loop and spilled: see merit_pass)
+#endif
                     double *rec = v2 + (size_t)(k - k0) * LS;
                     if (k < Nl) {
                         const double *g1 = G1 + (size_t)k * W1;
@@ -2840,6 +2843,11 @@ struct Engine {
                 double acc = 0.0;
                 if (g < na) {
                 for (int k = k0 + lane; k <= k1; k += LPG) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MPCB_NO_LICM_BLOCK)
+                    // (the parameter block is read from LDS where it is used: hoisted out of this loop -- ~60 values -- it is spilled to
+                    // scratch memory as a whole by the 256-register builds)
+                    asm volatile("" ::: "memory");
+#endif
                     const double *r1 = v1 + (size_t)(k - k0) * L1, *rn = r1 + L1;
                     const double *mw = vm + (size_t)(k - k0) * LMW;
                     double *xx = vt + ((size_t)g * CH + (k - k0)) * LVT, *rec = xx + 12;   // task_lin<false> only writes rec[O_R..O_R+4]

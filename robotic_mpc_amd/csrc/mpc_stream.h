@@ -2078,6 +2078,9 @@ SE_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
     const SWs w = sm.w;
     double acc = 0.0;
     for (int k0 = 0; k0 <= N; k0 += WAVE) {
+#ifndef MPCB_NO_LICM_BLOCK
+        asm volatile("" ::: "memory");     // (parameters are read where they are used, not hoisted out of the loop and spilled: mpc_core.h merit_pass)
+#endif
         const int k = k0 + lane;
         if (k > N) continue;
         MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)k * w.ld);
