@@ -66,10 +66,11 @@ extern "C" {
 /* Measured crossovers, N=100, 600 steps, one MI355X, fast path of the QP solve on, the throughput engine's first pass of a step
  * item-parallel (profiles/r04_engine_sweep2.txt; latency engine two simulations per CU vs throughput engine, steps/s).  SQP_RTI: 1024
  * simulations 2.40 M vs 2.10 M, 1280: 2.34 M vs 2.55 M, 2048: 2.55 M vs 3.69 M, 4096: 2.67 M vs 4.08 M.  Full SQP: 2048 simulations
- * 474 k vs 435 k, 2560: 447 k vs 489 k, 4096: 503 k vs 601 k.  Short full-SQP runs (profiles/r04_sqp_short_runs.txt): 2560 x 100 steps 112 k vs
- * 111 k, 3072 x 100: 119 k vs 121 k, 2560 x 200: 192 k vs 208 k, 4096 x 200: 224 k vs 261 k. */
-#define MPCB_STREAM_MIN_BATCH_SQP 2560   /* full SQP: from this many simulations on ... */
-#define MPCB_STREAM_MIN_STEPS_SQP 200    /* ... for runs of at least this many closed-loop steps */
+ * 474 k vs 435 k, 2560: 447 k vs 489 k, 4096: 503 k vs 601 k -- and once more at the round's last kernels (joint-angle sincos, SQP merit pass without
+ * spills: the latency engine gained more; profiles/r04_engine_sweep3.txt): 2560: 620 k vs 600 k, 3072: 665 k vs 670 k, 3584: 686 k vs 715 k, 4096: 723 k
+ * vs 758 k; 200 steps: 3072: 283 k vs 244 k, 4096: 308 k vs 307 k.  SQP_RTI there: 1280: 2.49 M vs 2.60 M, 4096: 4.23 M on the throughput engine. */
+#define MPCB_STREAM_MIN_BATCH_SQP 3072   /* full SQP: from this many simulations on ... */
+#define MPCB_STREAM_MIN_STEPS_SQP 300    /* ... for runs of at least this many closed-loop steps */
 #define MPCB_STREAM_MIN_BATCH 1280
 
 typedef struct mpcb_handle mpcb_handle;

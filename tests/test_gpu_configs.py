@@ -159,13 +159,13 @@ def test_config3_full_sqp_batch512_matches_oracle(eng, orc, ur10, ur10_rb):
 
 def test_config3_full_sqp_large_batch_takes_the_work_queue_and_matches_oracle(orc, ur10, ur10_rb, monkeypatch):
     """BASELINE configs[3], 2560 full-SQP simulations over all 600 closed-loop steps on the THROUGHPUT engine's work-queue
-    launch.  (Full SQP goes to the throughput engine from MPCB_STREAM_MIN_BATCH_SQP = 2560 simulations x >= 200 steps -- round 4, with
-    its item-parallel NLP residual pass; 3328 in round 3 -- the engine is still named here, and the default pick at both sides of that
+    launch.  (Full SQP goes to the throughput engine from MPCB_STREAM_MIN_BATCH_SQP = 3072 simulations x >= 300 steps -- round 4, both
+    engines re-measured at its last kernels; 3328 in round 3 -- the engine is still named here, and the default pick at both sides of that
     threshold is asserted first.)  Same random coefficients as the batch-512 test; spot
     checks against the oracle with strict parity up to the first flagged step."""
     from robotic_mpc_amd import config, engine
 
-    for n, steps, want in ((2048, 600, 0), (2560, 600, 1), (4096, 100, 0)):
+    for n, steps, want in ((2560, 600, 0), (3072, 600, 1), (4096, 100, 0)):
         assert engine.engine_for(n, 100, steps, "SQP") == want, (n, steps)
     monkeypatch.setenv("MPCB_ENGINE", "stream")
     eng = engine.MpcBatchEngine(0)
