@@ -117,8 +117,10 @@ MPC_HD void kin_eval(const Robot &rb, const double *q, Kin &k)
 // (LINR) stage record: rec[O_R..] = r, rec[O_GQ..] = Gq, rec[O_GV..] = gv5.
 // rec_r receives r, rec_g the Jacobian entries (the same record for both, or r kept in registers while the
 // Jacobian goes straight to memory).
-template <bool JAC>
-MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *rec_r, double *rec_g)
+// (PG: the Jacobian's destination keeps its address space -- a `double *` parameter would turn the throughput engine's stores to its HBM
+// record into flat_store, which occupy the LDS queue as well)
+template <bool JAC, class PG>
+MPC_HD void task_lin(const Robot &rb, const InstParams &P, const double *q, const double *qd, double *rec_r, PG rec_g)
 {
     Kin k;
     kin_eval(rb, q, k);

@@ -1928,7 +1928,7 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
 #endif
         if (k < N) {
             double rl[10];                                             // r | Y; the Jacobian goes straight to the record
-            task_lin<true>(rb, P, xx, xx + 6, rl, (double *)r2);
+            task_lin<true>(rb, P, xx, xx + 6, rl, r2);
 #pragma unroll
             for (int i = 0; i < NTASK; i++) rl[O_Y + i] = P.w_task[i] * rl[O_R + i];
 #pragma unroll
