@@ -78,7 +78,8 @@ constexpr int O_NPI = 0, O_NLAM = 12, O_NT = 36, O_TX = 60, O_TU = 72, O_MW = 78
 constexpr int STAGE_DOUBLES = W1 + W2 + W3 + W4 + W5;
 // [0..11] plant state z, [12] cost of the held linearisation, [13..24] merit weights of the x0
 // constraint, [25] linearisation-valid flag, [26] fast path: QPs left before the next attempt, [27] length of the
-// current suspension, [32..47] profile counters (diagnostic build)
+// current suspension, [28] throughput engine, SQP_RTI: the slot of the stage records that holds the QP iterate (0: G1, 1: G3),
+// [32..47] profile counters (diagnostic build)
 constexpr int STATE_DOUBLES = 64;
 constexpr int NPROF = 16;
 

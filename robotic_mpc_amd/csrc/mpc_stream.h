@@ -1019,8 +1019,10 @@ SE_PASS IpmNorms residual_items(double a)
 // ONE function for every place the norms are formed (fused with the right-hand side, alone at the end of a launch / work item, before
 // an interior-point solve), so a run cut into work items reproduces the plain launch bit for bit.
 // SQPM (full SQP): the norms use the blended NLP multipliers of G5 (NPI | NLAM | NT: the same relative layout as QPI | QLAM | QT of G1).
+// `slot` (SQP_RTI): where the QP iterate, hence its multipliers, sits in the stage record -- 0: G1 [QPI | QLAM | QT], 1: G3 [DPI | DLAM | DT]
+// (an accepted fast-path candidate that has become the iterate by a flip of the index, fast_commit / ipm_solve).
 template <bool NORMS, bool RHS, bool SQPM = false>
-SE_PASS void rti_items(int xsel, double *out5)
+SE_PASS void rti_items(int xsel, double *out5, int slot = 0)
 {
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
@@ -1032,7 +1034,7 @@ SE_PASS void rti_items(int xsel, double *out5)
                                                     (unsigned)uni((int)(unsigned long long)w.G1));
     auto rec = [&](int k, int col) { return (MPC_GLOBAL double *)(gb + (unsigned)((k * LD + col) << 3)); };
     constexpr int C2 = W1;
-    const int CM = SQPM ? uni((int)(w.G5 - w.G1)) + O_NPI : O_QPI;     // column of the multipliers [pi 12 | lam 24 | t 24] in the stage record
+    const int CM = SQPM ? uni((int)(w.G5 - w.G1)) + O_NPI : (uni(slot) ? W1 + W2 + O_DPI : O_QPI);     // column of the multipliers [pi 12 | lam 24 | t 24] in the stage record
     auto gld = [](const MPC_GLOBAL double *p) { return *p; };
     auto gst = [](MPC_GLOBAL double *p, double v) { *p = v; };
     // stage 0's joint items are lanes 0..5 of the first batch: their x_hat entries wait in registers (an LDS read inside the item loop
@@ -1435,8 +1437,12 @@ struct StepInfo {
 // FAST (bound-inactive fast path, mpc_ipm.h): the step is the candidate solution of the equality-constrained QP; the lagging role
 // forms the candidate's slacks (-> DT; DLAM = 0) from the NLP iterate's u, q instead of dlam / dt, and `alpha` comes back 1.0 when
 // every bounded component clears its bounds by ipm::FAST_MARGIN (and nothing is NaN), else 0.0.
+// FAST: `cand` = where the candidate goes: 1 -- the Newton-step slots of G3 (DW | DPI | DLAM | DT), 0 -- the QP-iterate slots of G1
+// (QW | QPI | QLAM | QT), whichever does NOT hold the QP iterate at the moment (SQP_RTI keeps the iterate in either and flips on
+// acceptance instead of copying, see ipm_solve); the multiplier step is stored UNSHIFTED there (dpi_k with stage k, as QPI is), so that the
+// 78 doubles of a stage are the QP iterate as they stand.
 template <class FT, bool AFFINE, bool FAST = false>
-SE_PASS StepInfo forward_pass()
+SE_PASS StepInfo forward_pass(int cand = 1)
 {
     static_assert(!FAST || !AFFINE, "the fast path takes the full step");
     SSmem &sm = g_ssm;
@@ -1456,6 +1462,7 @@ SE_PASS StepInfo forward_pass()
         if (FAST) { const Seg si[2] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, 0, 18)}; bin.setup(si, lane); }
         else { const Seg si[3] = {segf<FT>(w.G4, w.ld, 0, LF), segd(w.G1, w.ld, O_QLAM, 48), segd(w.G3, w.ld, O_RD, 48)}; bin.setup(si, lane); }
         if (AFFINE) { const Seg so[1] = {segd(w.G3, w.ld, O_DLAM, 48)}; bout.setup(so, lane); }
+        else if (FAST && uni(cand) == 0) { const Seg so[1] = {segd(w.G1, w.ld, O_QW, 78)}; bout.setup(so, lane); }
         else { const Seg so[1] = {segd(w.G3, w.ld, O_DW, 78)}; bout.setup(so, lane); }
         bout.seek(0, 1);                                           // (stage k stores row k-1, starting with row 0)
     }
@@ -1513,7 +1520,12 @@ SE_PASS StepInfo forward_pass()
         } else if (lane >= 16 && lane < 22 && k <= N) {
             o[lane - 16] = k < N ? -(double)kd : 0.0;               // du_k (stage N has no input: 0)
         } else if (!AFFINE && lane >= 32 && lane < 44 && k <= N) {
-            o[18 + (lane - 32)] = k >= 1 ? (double)kd : 0.0;        // DPI slot of stage k holds dpi_{k-1}
+            if (FAST) {
+                if (k >= 1) op[18 + (lane - 32)] = (double)kd;      // dpi_{k-1} goes with stage k-1, whose row is still here (stored below)
+                if (k == N) o[18 + (lane - 32)] = 0.0;              // no multiplier beyond the last dynamics
+            } else {
+                o[18 + (lane - 32)] = k >= 1 ? (double)kd : 0.0;    // DPI slot of stage k holds dpi_{k-1}
+            }
         } else if (lane >= 48 && lane < 60 && k >= 1) {
             const int j = jl, kp = k - 1;
             const double dv = dvl;                                  // du_{k-1}[j] or dq_{k-1}[j-6]
@@ -1706,10 +1718,14 @@ SE_PASS void corrector_pass(double sigma_mu)
 }
 
 // =============================================================================================== fast path: commit
-// The accepted candidate becomes the QP iterate (mpc_core.h fast_commit): (QW | QPI) <- (DW | DPI), QLAM <- 0, QT <- the slacks in DT.
-// Item-parallel, straight from / to the stage records.  The x part of stage 0 is the embedded x_hat - x_0 (the sweep's dx_0 is 0);
-// stage 0's y already holds W (r + G [dx0]) from the right-hand-side pass.
-SE_PASS void fast_commit()
+// The accepted candidate becomes the QP iterate.  SQP_RTI does not copy anything for that: the forward sweep left the candidate in
+// whichever of the two 78-double slots of a stage (G1 [QW | QPI | QLAM | QT], G3 [DW | DPI | DLAM | DT]: same layout) does not hold the
+// iterate, unshifted, and ipm_solve flips the slot index (`cur`, kept in the workspace, state[28]); lin_pass and rti_items read the iterate
+// through it.  This pass is what remains: the COPY of the G3 slot into the G1 slot -- 39 16-byte items per stage -- that puts the iterate
+// where the interior-point passes and the SQP line search expect it: before an interior-point solve when the iterate sits in G3
+// (rare), and at every acceptance in full SQP (`embed_x0`: stage 0's x part is x_hat - x_0 there, lbx_0 = ubx_0; SQP_RTI's lin_pass
+// has written it already).
+SE_PASS void fast_commit(bool embed_x0)
 {
     SSmem &sm = g_ssm;
     const int lane = threadIdx.x;
@@ -1723,14 +1739,14 @@ SE_PASS void fast_commit()
     wait_vm<0>();
     fence();
     {
-        constexpr int IPS = 15, R = 8;
+        constexpr int IPS = 39, R = 8;
         const int items = NS * IPS;
         for (int base = 0; base < items; base += R * WAVE) {
             D2 stp[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, c = 2 * (e - k * IPS);
-                stp[r] = *(MPC_GLOBAL const D2 *)(rec(c >= 18 ? imin(k + 1, N) : k, c) + C3 + O_DW);
+                stp[r] = *(MPC_GLOBAL const D2 *)(rec(k, c) + C3 + O_DW);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -1738,33 +1754,10 @@ SE_PASS void fast_commit()
                 if (e < items) {
                     const int k = e / IPS, c = 2 * (e - k * IPS);
                     D2 v = stp[r];
-                    if (c >= 18 && k >= N) { v.x = 0.0; v.y = 0.0; }             // no multiplier beyond the last dynamics
-                    if (k == 0 && c >= 6 && c < 18) {                            // x_0 = x_hat (lbx_0 = ubx_0): the sweep's dx_0 is 0
+                    if (embed_x0 && k == 0 && c >= 6 && c < 18) {                // x_0 = x_hat (lbx_0 = ubx_0): the sweep's dx_0 is 0
                         v.x = sm.xhat[c - 6] - *(rec(0, c - 6) + O_X); v.y = sm.xhat[c - 5] - *(rec(0, c - 5) + O_X);
                     }
                     *(MPC_GLOBAL D2 *)(rec(k, c) + O_QW) = v;
-                }
-            }
-        }
-    }
-    {
-        constexpr int IPS = 24, R = 8;
-        const int items = NS * IPS;
-        for (int base = 0; base < items; base += R * WAVE) {
-            D2 stp[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int e = imin(base + r * WAVE + lane, items - 1), k = e / IPS, q = 2 * (e - k * IPS);
-                stp[r] = *(MPC_GLOBAL const D2 *)(rec(k, q >= 24 ? q - 24 : 0) + C3 + O_DT);
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int e = base + r * WAVE + lane;
-                if (e < items) {
-                    const int k = e / IPS, q = 2 * (e - k * IPS);
-                    D2 v = stp[r];
-                    if (q < 24) { v.x = 0.0; v.y = 0.0; }
-                    *(MPC_GLOBAL D2 *)(rec(k, q) + O_QLAM) = v;
                 }
             }
         }
@@ -1784,12 +1777,18 @@ SE_PASS void fast_commit()
 #endif
 // `fast`: [0] QPs left before the next fast-path attempt, [1] length of the current suspension (ipm::fast_backoff); the fast path
 // runs in fp64 only -- ONE fp32 Riccati solve is not a solution to qp_tol (the fp32 leg refines through the fp64 residuals of the loop).
+// `cur` (SQP_RTI; null = full SQP): which slot of the stage records holds the QP iterate -- 0: G1 [QW..QT], 1: G3 [DW..DT] (fast_commit
+// comment).  An accepted fast-path candidate becomes the iterate by flipping it; the interior-point loop wants the iterate in G1.
 template <class FT>
-SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_prev = nullptr)
+SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_prev = nullptr, int *cur = nullptr)
 {
     SSmem &sm = g_ssm;
     const double tol = sm.P.qp_tol;
     int tried = 0;
+#ifdef MPCB_STREAM_SEQ_RES      // (A/B builds: the sequential passes read the iterate in G1 only)
+    cur = nullptr;
+#endif
+    const int slot = cur ? *cur : 0;
     if (sizeof(FT) == 8 && uni(sm.P.fast_off == 0.0 ? 1 : 0)) {
         if (fast[0] > 0) fast[0]--;
         else {
@@ -1798,7 +1797,7 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
 #ifdef MPCB_STREAM_SEQ_RES
             if (nlp_prev) residual_pass<4>(0.0, nlp_prev); else residual_pass<3>(0.0);
 #else
-            if (nlp_prev) rti_items<true, true>(1, nlp_prev); else rti_items<false, true>(0, nullptr);
+            if (nlp_prev) rti_items<true, true>(1, nlp_prev, slot); else rti_items<false, true>(0, nullptr);
 #endif
             SPROF_ADD(10, t_r);
             nlp_prev = nullptr;                                    // the previous step's residuals are done, whatever happens next
@@ -1806,11 +1805,12 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
             fact_pass<FT, true>();
             SPROF_ADD(11, t_f);
             SPROF_T0(t_w);
-            const double ok = unid(forward_pass<FT, false, true>().alpha);
+            const double ok = unid(forward_pass<FT, false, true>(slot ^ 1).alpha);     // the candidate goes to the slot that is NOT the iterate
             SPROF_ADD(12, t_w);
             if (uni(ok > 0.5 ? 1 : 0)) {
                 SPROF_T0(t_c);
-                fast_commit();
+                if (cur) *cur = slot ^ 1;        // SQP_RTI: it IS the iterate now
+                else fast_commit(true);          // full SQP: copied to G1, x_0 embedded
                 SPROF_ADD(13, t_c);
 #ifdef MPCB_SPROF
                 if (threadIdx.x == 0) g_ssm.w.state[32 + 15] += 1.0;
@@ -1827,7 +1827,8 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
 #ifdef MPCB_STREAM_SEQ_RES
     IpmNorms r = nlp_prev ? residual_pass<2>(0.0, nlp_prev) : residual_pass<0>(0.0);
 #else
-    if (nlp_prev) rti_items<true, false>(1, nlp_prev);     // (the same items as everywhere else: see rti_items)
+    if (nlp_prev) rti_items<true, false>(1, nlp_prev, slot);     // (the same items as everywhere else: see rti_items)
+    if (cur && slot == 1) { fast_commit(false); *cur = 0; }      // the interior-point passes expect the iterate in G1 (this also overwrites a rejected candidate there)
     IpmNorms r = residual_pass<0>(0.0);
 #endif
     const double nc = unid(r.nc);
@@ -1888,7 +1889,9 @@ SE_DEV int ipm_solve(int qp_iter_max, int *iters_out, int *fast, double *nlp_pre
 // stage record, the L2 merges them into full lines).  Optionally applies the QP step first.
 // With `sqp_mult` the NLP multipliers are blended towards the QP's with the same step (acados
 // ocp_nlp_update_variables_sqp): N* += alpha (Q* - N*) on [pi | lam | t] (60 entries of G5).
-SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
+// `slot` (SQP_RTI: 0 / 1, full SQP: -1): where the QP iterate -- the step to apply -- sits (rti_items); in SQP_RTI stage 0's x part of it,
+// x_hat - x_0 (lbx_0 = ubx_0: the sweeps' dx_0 is 0), is formed AND written here, the only pass that has the x_0 it refers to.
+SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false, int slot = -1)
 {
     SSmem &sm = g_ssm;
     const InstParams &P = sm.P;
@@ -1909,7 +1912,19 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false)
         for (int i = 0; i < 12; i++) xx[i] = r1[O_X + i];
 #pragma unroll
         for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i];
-        if (do_update) {
+        if (do_update && uni(slot) >= 0) {
+            MPC_GLOBAL double *qw = uni(slot) ? (MPC_GLOBAL double *)((char *)w.G3 + (size_t)k * w.ld) + O_DW : r1 + O_QW;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                double st = qw[6 + i];
+                if (k == 0) { st = sm.xhat[i] - xx[i]; qw[6 + i] = st; }
+                xx[i] += alpha * st; r1[O_X + i] = xx[i];
+            }
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { uu[i] += alpha * qw[i]; r1[O_U + i] = uu[i]; }
+            }
+        } else if (do_update) {
 #pragma unroll
             for (int i = 0; i < 12; i++) { xx[i] += alpha * r1[O_QW + 6 + i]; r1[O_X + i] = xx[i]; }
             if (k < N) {
@@ -2247,6 +2262,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     bool res_pending = false;          // SQP_RTI: cost / residual norms of the previous step are formed by this step's first pass
     double lin_cost = 0.0;
     int fast[2] = {0, 0};              // fast path: QPs left before the next attempt, length of the current suspension
+    int cur = 0;                       // SQP_RTI: slot of the stage records that holds the QP iterate (fast_commit comment)
     int log_lo = step0 == 0 ? 0 : step0 + 1;
     if (step0 == 0) {
         // acados initial guess: x_k = x0, u_k = 0, all multipliers / QP memory 0
@@ -2267,7 +2283,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
         if (lane < NX) sm.xhat[lane] = w.state[lane];
         lin_cost = unid(w.state[12]);
         lin_valid = uni(w.state[25] != 0.0 ? 1 : 0) != 0;
-        fast[0] = uni((int)w.state[26]); fast[1] = uni((int)w.state[27]);
+        fast[0] = uni((int)w.state[26]); fast[1] = uni((int)w.state[27]); cur = uni((int)w.state[28]);
         fence();
     }
     for (int i = step0; i < step1; i++) {
@@ -2283,12 +2299,12 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
             if (!lin_valid) {
                 lin_pass(0.0, false); __builtin_amdgcn_s_waitcnt(0); fence();
                 double o5[5];
-                rti_items<true, false>(0, o5);
+                rti_items<true, false>(0, o5, cur);
                 lin_cost = unid(o5[0]);
             }
 #endif
             double nlp_prev[5];
-            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, fast, res_pending ? nlp_prev : nullptr);
+            const int qs = ipm_solve<FT>(pb.qp_iter_max, &qp_iter, fast, res_pending ? nlp_prev : nullptr, &cur);
             if (res_pending) {
                 // cost and residual norms of step i-1, evaluated by this step's first pass
                 if (lane == 8) out.cost[sbase + i - 1] = nlp_prev[0];
@@ -2303,7 +2319,11 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
             if (!ok) status = 4;                                       // ACADOS_QP_FAILURE, iterate untouched
             __builtin_amdgcn_s_waitcnt(0);
             SPROF_T0(tl);
+#ifdef MPCB_STREAM_SEQ_RES
             lin_pass(1.0, ok);
+#else
+            lin_pass(1.0, ok, false, cur);
+#endif
             __builtin_amdgcn_s_waitcnt(0);                             // the records written lane by lane are complete before they are streamed
             fence();
             SPROF_ADD(8, tl);
@@ -2317,7 +2337,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
                 cost = unid(nlp_res_pass<false>(res4));                // last step of this launch / work item
 #else
                 double o5[5];
-                rti_items<true, false>(0, o5);                         // last step of this launch / work item
+                rti_items<true, false>(0, o5, cur);                    // last step of this launch / work item
                 cost = unid(o5[0]); res4[0] = o5[1]; res4[1] = o5[2]; res4[2] = o5[3]; res4[3] = o5[4];
 #endif
             }
@@ -2431,7 +2451,7 @@ SE_DEV void rollout(const Problem &pb, const InstParams *params, const Robot *rb
     }
     if (log_lo <= step1) log_flush(out, inst, T1, log_lo, step1);
     if (lane < NX) w.state[lane] = sm.xhat[lane];
-    if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; w.state[26] = fast[0]; w.state[27] = fast[1]; }
+    if (lane == 12) { w.state[12] = lin_cost; w.state[25] = lin_valid ? 1.0 : 0.0; w.state[26] = fast[0]; w.state[27] = fast[1]; w.state[28] = cur; }
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
