@@ -1914,15 +1914,27 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false, int s
         for (int i = 0; i < 6; i++) uu[i] = r1[O_U + i];
         if (do_update && uni(slot) >= 0) {
             MPC_GLOBAL double *qw = uni(slot) ? (MPC_GLOBAL double *)((char *)w.G3 + (size_t)k * w.ld) + O_DW : r1 + O_QW;
+            // (every load before the first store: a load issued behind a store waits for the store's acknowledgement, ~1 us each)
+            double st[18];
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                double st = qw[6 + i];
-                if (k == 0) { st = sm.xhat[i] - xx[i]; qw[6 + i] = st; }
-                xx[i] += alpha * st; r1[O_X + i] = xx[i];
+            for (int i = 0; i < 18; i++) st[i] = qw[i];
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) st[6 + i] = sm.xhat[i] - xx[i];
             }
+#pragma unroll
+            for (int i = 0; i < 12; i++) xx[i] += alpha * st[6 + i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) uu[i] += alpha * st[i];
+#pragma unroll
+            for (int i = 0; i < 12; i++) r1[O_X + i] = xx[i];
             if (k < N) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) { uu[i] += alpha * qw[i]; r1[O_U + i] = uu[i]; }
+                for (int i = 0; i < 6; i++) r1[O_U + i] = uu[i];
+            }
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) qw[6 + i] = st[6 + i];
             }
         } else if (do_update) {
 #pragma unroll
