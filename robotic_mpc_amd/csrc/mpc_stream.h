@@ -111,6 +111,9 @@ struct SSmem {
 #endif
 static_assert(sizeof(SSmem) <= 163840 / (4 * MPCB_STREAM_WPE), "MPCB_STREAM_WPE wavefronts per SIMD share the 160 KiB of a CU");
 
+#ifndef MPCB_RTI_R
+#define MPCB_RTI_R 2
+#endif
 #define SE_DEV __device__ __forceinline__
 #define SE_PASS __device__ __noinline__
 
@@ -1045,7 +1048,7 @@ SE_PASS void rti_items(int xsel, double *out5, int slot = 0)
     wait_vm<0>();
     fence();
     double csum = 0.0, n_s = 0, n_e = 0, n_i = 0, n_c = 0;
-    constexpr int R = 2;
+    constexpr int R = MPCB_RTI_R;
     const int items = NS * 6;
     const double dt = P.dt;
     for (int base = 0; base < items; base += R * WAVE) {

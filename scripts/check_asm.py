@@ -54,7 +54,7 @@ BUDGET = {
     "DevExecILi8ELi1EEE9log_state": 8, "DevExecILi4ELi2EEE9log_state": 8, "DevExecILi4ELi1EEE9log_state": 8,
     "10merit_pass": 210, "se8lin_pass": 8, "se9log_state": 8,
     "18mpc_rollout_kernelILi8ELi1E": 340, "18mpc_rollout_kernelILi4ELi2E": 330, "18mpc_rollout_kernelILi4ELi1E": 258,
-    "17mpc_stream_kernelId": 150, "17mpc_stream_kernelIf": 150,
+    "17mpc_stream_kernelId": 160, "17mpc_stream_kernelIf": 160,
 }
 
 
