@@ -1948,7 +1948,18 @@ SE_PASS void lin_pass(double alpha, bool do_update, bool sqp_mult = false, int s
             }
             if (sqp_mult) {
                 MPC_GLOBAL double *r5 = (MPC_GLOBAL double *)((char *)w.G5 + (size_t)k * w.ld);
-                for (int i = 0; i < 60; i++) r5[i] += alpha * (r1[O_QPI + i] - r5[i]);   // NPI | NLAM | NT <- QPI | QLAM | QT
+                // NPI | NLAM | NT <- QPI | QLAM | QT, in three blocks of 20 with every load of a block before its first store (load / load /
+                // store per entry made each of the 60 loads wait for the store before it, ~1 us each)
+#pragma unroll
+                for (int b0 = 0; b0 < 60; b0 += 20) {
+                    double q_[20], n_[20];
+#pragma unroll
+                    for (int i = 0; i < 20; i++) { q_[i] = r1[O_QPI + b0 + i]; n_[i] = r5[b0 + i]; }
+#pragma unroll
+                    for (int i = 0; i < 20; i++) n_[i] += alpha * (q_[i] - n_[i]);
+#pragma unroll
+                    for (int i = 0; i < 20; i++) r5[b0 + i] = n_[i];
+                }
             }
         }
 #ifdef MPCB_SPROF_LIN
@@ -2116,11 +2127,27 @@ SE_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
         MPC_GLOBAL double *r1 = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)k * w.ld);
         MPC_GLOBAL double *rn = (MPC_GLOBAL double *)((char *)w.G1 + (size_t)(k < N ? k + 1 : k) * w.ld);
         MPC_GLOBAL double *mw = (MPC_GLOBAL double *)((char *)w.G5 + (size_t)k * w.ld) + O_MW;
+        // the 36 merit weights of the stage in registers; refreshed first when asked (Leineweber's rule) -- every load BEFORE the first
+        // store: load / load / store per weight made each of the 36 loads wait for the store before it (~1 us each, see lin_pass)
+        double mwv[36];
         if (update_weights) {
-            for (int i = 0; i < 36; i++) {
-                const double a = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
-                mw[i] = sqp_iter == 0 ? a : fmax(a, 0.5 * (mw[i] + a));
+            double a_[36];
+#pragma unroll
+            for (int i = 0; i < 36; i++) a_[i] = i < 12 ? fabs(r1[O_QPI + i]) : fabs(r1[O_QLAM + i - 12]);
+            if (sqp_iter == 0) {
+#pragma unroll
+                for (int i = 0; i < 36; i++) mwv[i] = a_[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 36; i++) mwv[i] = mw[i];
+#pragma unroll
+                for (int i = 0; i < 36; i++) mwv[i] = fmax(a_[i], 0.5 * (mwv[i] + a_[i]));
             }
+#pragma unroll
+            for (int i = 0; i < 36; i++) mw[i] = mwv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 36; i++) mwv[i] = mw[i];
         }
         double xx[12], uu[6], rec[8];
 #pragma unroll
@@ -2138,12 +2165,12 @@ SE_PASS double merit_pass(double alpha, bool update_weights, int sqp_iter)
                 s += 2.0 * P.w_u * uu[j] * uu[j] + P.w_qddot * qdd * qdd;
                 const double xnq = rn[O_X + j] + alpha * rn[O_QW + 6 + j];
                 const double xnv = rn[O_X + 6 + j] + alpha * rn[O_QW + 12 + j];
-                acc += mw[j] * fabs((xx[j] + P.a12[j] * xx[6 + j] + P.b1[j] * uu[j]) - xnq);
-                acc += mw[6 + j] * fabs((P.a22[j] * xx[6 + j] + P.b2[j] * uu[j]) - xnv);
+                acc += mwv[j] * fabs((xx[j] + P.a12[j] * xx[6 + j] + P.b1[j] * uu[j]) - xnq);
+                acc += mwv[6 + j] * fabs((P.a22[j] * xx[6 + j] + P.b2[j] * uu[j]) - xnv);
                 const double vl = P.umin[j] - uu[j], vu = uu[j] - P.umax[j];
-                acc += mw[12 + j] * fmax(vl, 0.0) + mw[24 + j] * fmax(vu, 0.0);
+                acc += mwv[12 + j] * fmax(vl, 0.0) + mwv[24 + j] * fmax(vu, 0.0);
                 const double ql = P.qmin[j] - xx[j], qu = xx[j] - P.qmax[j], on = k >= 1 ? 1.0 : 0.0;
-                acc += on * (mw[18 + j] * fmax(ql, 0.0) + mw[30 + j] * fmax(qu, 0.0));
+                acc += on * (mwv[18 + j] * fmax(ql, 0.0) + mwv[30 + j] * fmax(qu, 0.0));
             }
             acc += 0.5 * P.dt * s;
         }

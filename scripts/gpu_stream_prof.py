@@ -10,7 +10,7 @@ ch = robots.builtin_chain("ur10")
 from robotic_mpc_amd import build as _b
 eng = engine.MpcBatchEngine(0, lib_path=_b.build_variant("sprof_lin" if os.environ.get("LIN") else "sprof", ["MPCB_SPROF"] + (["MPCB_SPROF_LIN"] if os.environ.get("LIN") else [])))     # (built on demand)
 for B in [int(v) for v in sys.argv[1:]] or [1024, 2048]:
-    cfgs = bench.workload_configs(B, 100, float(os.environ.get("TSIM", "0.5")), seed=1, solver="SQP_RTI")
+    cfgs = bench.workload_configs(B, 100, float(os.environ.get("TSIM", "0.5")), seed=1, solver=os.environ.get("SWEEP_SOLVER", "SQP_RTI"))
     pb, bufs = eng.run_device(cfgs, ch)
     ms = sum(eng.last_kernel_ms)
     out = np.zeros(16)
