@@ -68,7 +68,8 @@ extern "C" {
  * simulations 2.40 M vs 2.10 M, 1280: 2.34 M vs 2.55 M, 2048: 2.55 M vs 3.69 M, 4096: 2.67 M vs 4.08 M.  Full SQP: 2048 simulations
  * 474 k vs 435 k, 2560: 447 k vs 489 k, 4096: 503 k vs 601 k -- and once more at the round's last kernels (joint-angle sincos, SQP merit pass without
  * spills: the latency engine gained more; profiles/r04_engine_sweep3.txt): 2560: 620 k vs 600 k, 3072: 665 k vs 670 k, 3584: 686 k vs 715 k, 4096: 723 k
- * vs 758 k; 200 steps: 3072: 283 k vs 244 k, 4096: 308 k vs 307 k.  SQP_RTI there: 1280: 2.49 M vs 2.60 M, 4096: 4.23 M on the throughput engine. */
+ * vs 758 k; 200 steps: 3072: 283 k vs 244 k, 4096: 308 k vs 307 k (after the throughput engine's last SQP fixes, r04_engine_sweep4.txt: 2560: 618 k
+ * vs 615-647 k, 3072: 661-671 k vs 685-713 k, 4096: 845-870 k on the throughput engine; 3072 x 200 steps: 282 k vs 261 k -- thresholds unchanged).  SQP_RTI there: 1280: 2.49 M vs 2.60 M, 4096: 4.23 M on the throughput engine. */
 #define MPCB_STREAM_MIN_BATCH_SQP 3072   /* full SQP: from this many simulations on ... */
 #define MPCB_STREAM_MIN_STEPS_SQP 300    /* ... for runs of at least this many closed-loop steps */
 #define MPCB_STREAM_MIN_BATCH 1280
